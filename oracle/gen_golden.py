@@ -1,0 +1,278 @@
+"""
+Generate the golden fixtures under tests/golden/ by importing the *reference*
+(read-only, /root/reference) in the build container, and check the CPU oracle
+(oracle/ref_cpu.py) against it on the same inputs.
+
+    PYTHONPATH=/root/reference:/root/repo python oracle/gen_golden.py
+
+The reference never travels to the GPU box; only the .npz vectors written here
+do.  Fixtures are data only (inputs, expected outputs, seeds, checksums).
+"""
+
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_cpu  # noqa: E402
+from vq_voice_swap_amd.det_init import det_init_  # noqa: E402
+
+from vq_voice_swap.diffusion_model import DiffusionModel  # noqa: E402  (reference)
+from vq_voice_swap.models.unet import ResBlock  # noqa: E402  (reference)
+from vq_voice_swap.vq_vae import VQVAE  # noqa: E402  (reference)
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(8)
+
+
+def seeded(shape, seed, scale=1.0):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def state_of(model):
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    return sd
+
+
+def det_model(model):
+    det_init_(model.state_dict().items())
+    model.eval()
+    return model
+
+
+def check(name, ref, ours, tol=1e-6):
+    err = (ref - ours).abs().max().item()
+    scale = ref.abs().max().item()
+    print(f"  oracle vs reference [{name}]: max|diff|={err:.3e} (max|ref|={scale:.3e})")
+    assert err <= tol * max(1.0, scale), f"oracle diverges from reference on {name}"
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: (v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrays.items()})
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def probe_stats(t):
+    flat = t.flatten()
+    idx = torch.linspace(0, flat.numel() - 1, 16).long()
+    return np.concatenate([[t.mean().item(), t.pow(2).mean().sqrt().item()], flat[idx].numpy()]).astype(np.float32)
+
+
+# ---------------------------------------------------------------- F1 ResBlocks
+def gen_resblocks():
+    cases = [
+        dict(name="same32", cin=32, cout=32, scale=1.0, dil=2, emb=128, L=256),
+        dict(name="widen32_64", cin=32, cout=64, scale=1.0, dil=2, emb=128, L=256),
+        dict(name="down64", cin=64, cout=64, scale=0.5, dil=2, emb=128, L=256),
+        dict(name="up64", cin=64, cout=64, scale=2.0, dil=2, emb=128, L=128),
+        dict(name="cat96_32", cin=96, cout=32, scale=1.0, dil=2, emb=128, L=256),
+        dict(name="mid_dil32", cin=64, cout=64, scale=1.0, dil=32, emb=128, L=250),
+        dict(name="noemb_enc", cin=32, cout=64, scale=1.0, dil=2, emb=None, L=256),
+    ]
+    out = {}
+    for i, c in enumerate(cases):
+        blk = ResBlock(channels=c["cin"], emb_channels=c["emb"],
+                       out_channels=c["cout"] if c["cout"] != c["cin"] else None,
+                       scale_factor=c["scale"], dilation=c["dil"])
+        prefix = "blk." + c["name"]
+        det_init_((prefix + "." + k, v) for k, v in blk.state_dict().items())
+        blk.eval()
+        x = seeded((2, c["cin"], c["L"]), 100 + i)
+        emb = seeded((2, c["emb"]), 200 + i) if c["emb"] else None
+        with torch.no_grad():
+            y = blk(x, emb) if emb is not None else blk(x)
+        sd = {prefix + "." + k: v for k, v in blk.state_dict().items()}
+        spec = dict(cin=c["cin"], cout=c["cout"], scale=c["scale"], dil=c["dil"])
+        y2 = ref_cpu.res_block(x, sd, prefix, spec, emb)
+        check("resblock " + c["name"], y, y2)
+        out[c["name"] + ".x"] = x
+        if emb is not None:
+            out[c["name"] + ".emb"] = emb
+        out[c["name"] + ".y"] = y
+        out[c["name"] + ".spec"] = np.array([c["cin"], c["cout"], c["scale"], c["dil"], c["emb"] or 0, c["L"]], dtype=np.float64)
+    save("f1_resblocks", **out)
+
+
+# ---------------------------------------------------------------- F3 whole unet32
+def gen_unet32():
+    model = det_model(DiffusionModel("unet", 32))
+    sd = state_of(model)
+    x = seeded((2, 1, 64000), 1)
+    ts = torch.tensor([0.3, 0.9])
+    probes = {}
+
+    def hook_for(name):
+        def fn(mod, inp, outp):
+            probes[name] = probe_stats(outp)
+        return fn
+
+    hs = [model.predictor.in_conv.register_forward_hook(hook_for("in_conv"))]
+    for grp in ("down_blocks", "middle_blocks", "up_blocks"):
+        for i, b in enumerate(getattr(model.predictor, grp)):
+            hs.append(b.register_forward_hook(hook_for(f"{grp}.{i}")))
+    with torch.no_grad():
+        eps = model.predictor(x, ts)
+    for h in hs:
+        h.remove()
+    oprobes = {}
+    eps2 = ref_cpu.unet_predictor(sd, 32, x, ts, probe=lambda n, t: oprobes.__setitem__(n, probe_stats(t)))
+    check("unet32 eps", eps, eps2)
+    for k in probes:
+        if k == "in_conv" and "in_conv" not in oprobes:
+            continue
+        assert np.allclose(probes[k], oprobes[k], atol=1e-5, rtol=1e-5), k
+    names = sorted(probes.keys())
+    save("f3_unet32_forward", x_seed=1, ts=ts, eps=eps,
+         probe_names=np.array(names), probe_vals=np.stack([probes[n] for n in names]))
+    print(f"  eps rms={eps.pow(2).mean().sqrt().item():.4f}")
+    return model, sd
+
+
+# ---------------------------------------------------------------- F5 ddpm_previous
+def gen_ddpm_previous(model):
+    diff = model.diffusion
+    cases = [(1.0, 0.1), (0.5, 0.02), (0.02, 0.02), (0.37, 0.01), (0.9, 0.25)]
+    out = {}
+    for i, (t, step) in enumerate(cases):
+        x = seeded((2, 1, 4096), 300 + i)
+        eps = seeded((2, 1, 4096), 400 + i)
+        noise = seeded((2, 1, 4096), 500 + i)
+        ts = torch.tensor([t, t])
+        for mode, kw in (("plain", {}), ("sigma_large", dict(sigma_large=True)), ("constrain", dict(constrain=True))):
+            y = diff.ddpm_previous(x, ts, step, eps, noise=noise, **kw)
+            y2 = ref_cpu.ddpm_previous("exp", x, ts, step, eps, noise, **kw)
+            check(f"ddpm_previous t={t} {mode}", y, y2)
+            out[f"c{i}.{mode}"] = y
+        out[f"c{i}.x"], out[f"c{i}.eps"], out[f"c{i}.noise"] = x, eps, noise
+        out[f"c{i}.t_step"] = np.array([t, step])
+    # per-row timesteps + a tensor step (sample-time schedule form, diffusion.py:116-118)
+    x, eps, noise = seeded((2, 1, 4096), 390), seeded((2, 1, 4096), 490), seeded((2, 1, 4096), 590)
+    ts = torch.tensor([0.81, 0.25])
+    step = torch.tensor([0.036, 0.019])
+    y = diff.ddpm_previous(x, ts, step, eps, noise=noise, constrain=True)
+    y2 = ref_cpu.ddpm_previous("exp", x, ts, step, eps, noise, constrain=True)
+    check("ddpm_previous per-row", y, y2)
+    out.update({"row.x": x, "row.eps": eps, "row.noise": noise, "row.ts": ts, "row.step": step, "row.constrain": y})
+    save("f5_ddpm_previous", **out)
+
+
+# ---------------------------------------------------------------- F6 end-to-end sampler
+def run_ref_sampler(model, x_T, steps, noise_seed, constrain, t_map=None):
+    """Drive the reference's ddpm_sample with explicit per-step noise by patching randn_like."""
+    gen = torch.Generator().manual_seed(noise_seed)
+    noises = [torch.randn(x_T.shape, generator=gen) for _ in range(steps)]
+    it = iter(noises)
+    import vq_voice_swap.diffusion.diffusion as dmod
+    orig = torch.randn_like
+    calls = []
+
+    def fake_randn_like(t, *a, **k):
+        calls.append(1)
+        return next(it)
+
+    dmod.torch.randn_like = fake_randn_like
+    try:
+        x0 = model.diffusion.ddpm_sample(x_T, model.predictor, steps, constrain=constrain, schedule=t_map)
+    finally:
+        dmod.torch.randn_like = orig
+    assert len(calls) == steps - 1  # last iteration uses zeros (diffusion.py:127)
+    return x0, noises
+
+
+def gen_sampler(model, sd):
+    x_T = seeded((2, 1, 64000), 7)
+    out = {}
+    for tag, steps, constrain, tmap in (("s10_plain", 10, False, None), ("s10_constrain", 10, True, None),
+                                        ("s50_sq_constrain", 50, True, (lambda t: t ** 2))):
+        x0, noises = run_ref_sampler(model, x_T, steps, 11, constrain, tmap)
+        trace = []
+        x0b = ref_cpu.ddpm_sample("exp", x_T, lambda a, b: ref_cpu.unet_predictor(sd, 32, a, b), steps, noises,
+                                  constrain=constrain, t_map=tmap, trace=trace)
+        check("sampler " + tag, x0, x0b, tol=1e-5)
+        out[tag + ".x0"] = x0
+        out[tag + ".rms_trace"] = np.array([t.pow(2).mean().sqrt().item() for t in trace], dtype=np.float32)
+        out[tag + ".noise_checksum"] = np.array([n.double().sum().item() for n in noises])
+        print(f"  {tag}: x0 rms={x0.pow(2).mean().sqrt().item():.4f}")
+    save("f6_sampler_unet32", x_T_seed=7, noise_seed=11, **out)
+
+
+# ---------------------------------------------------------------- F4/F7/F8 VQ-VAE
+def gen_vqvae():
+    model = det_model(VQVAE(base_channels=32, pred_name="unet", num_labels=5))
+    with torch.no_grad():
+        model.vq.dictionary.copy_(seeded(model.vq.dictionary.shape, 77, 0.35))
+    sd = state_of(model)
+    # F7 encoder + VQ at full length
+    wav = seeded((2, 1, 64000), 21, 0.1).clamp(-1, 1)
+    with torch.no_grad():
+        z = model.encoder(wav)
+        codes = model.encode(wav)
+    z2 = ref_cpu.unet_encoder(sd, 32, wav)
+    check("encoder z", z, z2)
+    codes2 = ref_cpu.vq_encode(sd["vq.dictionary"], z2)
+    assert torch.equal(codes, codes2), "oracle VQ codes differ from reference"
+    d = ref_cpu.vq_distances(sd["vq.dictionary"], z.permute(0, 2, 1).reshape(-1, z.shape[1]))
+    top2 = torch.topk(d, 2, dim=-1, largest=False).values
+    gap = (top2[:, 1] - top2[:, 0]).reshape(2, -1)
+    print(f"  z rms={z.pow(2).mean().sqrt().item():.4f}; top-2 gap min={gap.min().item():.3e} median={gap.median().item():.3e}; distinct codes={codes.unique().numel()}")
+    # margin-guaranteed VQ set: dictionary rows + small noise
+    idx_m = torch.randint(0, 512, (2, 250), generator=torch.Generator().manual_seed(31))
+    zm = ref_cpu.vq_embed(sd["vq.dictionary"], idx_m) + 1e-3 * seeded((2, 512, 250), 32)
+    with torch.no_grad():
+        codes_m = model.vq(zm)["idxs"]
+    assert torch.equal(codes_m, idx_m)
+    assert torch.equal(ref_cpu.vq_encode(sd["vq.dictionary"], zm), idx_m)
+    save("f7_encoder_vq32", wav_seed=21, z=z.half(), z_rms=z.pow(2).mean().sqrt().item(), codes=codes, gap=gap,
+         margin_idx=idx_m, margin_noise_seed=32)
+    # F4 conditional predictor forward (cond + labels), short clip
+    x = seeded((2, 1, 4096), 41)
+    ts = torch.tensor([0.7, 0.15])
+    cond = ref_cpu.vq_embed(sd["vq.dictionary"], codes[:, :16])
+    labels = torch.tensor([3, 0])
+    with torch.no_grad():
+        eps = model.predictor(x, ts, cond=cond, labels=labels)
+    eps2 = ref_cpu.unet_predictor(sd, 32, x, ts, cond=cond, labels=labels)
+    check("vqvae predictor cond+labels", eps, eps2)
+    save("f4_cond_forward", x=x, ts=ts, codes16=codes[:, :16], labels=labels, eps=eps)
+    # F8 decode, 5 steps, constrain
+    import vq_voice_swap.diffusion.diffusion as dmod
+    import vq_voice_swap.vq_vae as vmod
+    x_T = seeded((2, 1, 4096), 51)
+    gen = torch.Generator().manual_seed(52)
+    noises = [torch.randn(x_T.shape, generator=gen) for _ in range(5)]
+    it = iter(noises)
+    orig_rl, orig_r = torch.randn_like, torch.randn
+    dmod.torch.randn_like = lambda t, *a, **k: next(it)
+    vmod.torch.randn = lambda *a, **k: x_T.clone()
+    try:
+        with torch.no_grad():
+            dec = model.decode(codes[:, :16], labels, steps=5, constrain=True)
+    finally:
+        dmod.torch.randn_like = orig_rl
+        vmod.torch.randn = orig_r
+    dec2 = ref_cpu.vqvae_decode(sd, 32, "exp", codes[:, :16], labels, 5, x_T, noises, constrain=True)
+    check("vqvae decode 5 steps", dec, dec2, tol=1e-5)
+    save("f8_vqvae_decode", x_T_seed=51, noise_seed=52, codes16=codes[:, :16], labels=labels, x0=dec)
+
+
+if __name__ == "__main__":
+    only = set(sys.argv[1:])
+    if not only or "resblocks" in only:
+        gen_resblocks()
+    if not only or only & {"unet32", "ddpm", "sampler"}:
+        m, sd = gen_unet32()
+        if not only or "ddpm" in only:
+            gen_ddpm_previous(m)
+        if not only or "sampler" in only:
+            gen_sampler(m, sd)
+    if not only or "vqvae" in only:
+        gen_vqvae()
+    print("ok")

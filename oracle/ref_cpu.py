@@ -1,0 +1,339 @@
+"""
+CPU oracle for the DDPM sampling hot path (TEST INFRASTRUCTURE ONLY).
+
+This file is a plain restatement, in stock torch fp32 CPU ops, of the algorithm
+the reference implements on this path.  It is *not* part of the product: only
+`tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may
+import it, and only as the checker / reported baseline.  The product path
+(`vq_voice_swap_amd`) never imports anything from `oracle/` and fails loudly if
+its HIP library is missing.
+
+Parity pin: the reference has no tests or golden vectors for this path
+(SURVEY.md section 4), so the oracle is pinned against outputs of the reference
+itself, imported in the build container (`oracle/gen_golden.py`), and the
+resulting vectors are committed under `tests/golden/`.
+
+Everything is functional: a model is (cfg dict, state dict with the reference's
+parameter names).  Reference citations are `file:line` under /root/reference.
+"""
+
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Optional
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+State = Dict[str, Tensor]
+
+CHANNEL_MULT = (1, 1, 2, 2, 2, 4, 4, 8, 8)  # vq_voice_swap/models/unet.py:20
+MIDDLE_DILATIONS = (4, 8, 16, 32)  # unet.py:21
+DEPTH_MULT = 2  # unet.py:22
+
+
+# --------------------------------------------------------------------------
+# topology (unet.py:51-111, 206-222)
+# --------------------------------------------------------------------------
+
+
+def predictor_block_specs(base: int) -> Dict[str, List[dict]]:
+    """Per-ResBlock (cin, cout, scale, dilation) for down / middle / up lists."""
+    down, middle, up = [], [], []
+    stack = [base]
+    cur = base
+    last = len(CHANNEL_MULT) - 1
+    for depth, mult in enumerate(CHANNEL_MULT):
+        for _ in range(DEPTH_MULT):
+            down.append(dict(cin=cur, cout=mult * base, scale=1.0, dil=2))
+            cur = mult * base
+            stack.append(cur)
+        if depth != last:
+            down.append(dict(cin=cur, cout=cur, scale=0.5, dil=2))
+            stack.append(cur)
+    for d in MIDDLE_DILATIONS:
+        middle.append(dict(cin=cur, cout=cur, scale=1.0, dil=d))
+    for depth in range(last, -1, -1):
+        mult = CHANNEL_MULT[depth]
+        for _ in range(DEPTH_MULT + 1):
+            skip = stack.pop()
+            up.append(dict(cin=cur + skip, cout=mult * base, scale=1.0, dil=2, cat=True))
+            cur = mult * base
+        if depth:
+            up.append(dict(cin=cur, cout=cur, scale=2.0, dil=2, cat=False))
+    return dict(down=down, middle=middle, up=up)
+
+
+def encoder_block_specs(base: int) -> List[dict]:
+    blocks = []
+    cur = base
+    last = len(CHANNEL_MULT) - 1
+    for depth, mult in enumerate(CHANNEL_MULT):
+        for _ in range(DEPTH_MULT):
+            blocks.append(dict(cin=cur, cout=mult * base, scale=1.0, dil=2))
+            cur = mult * base
+        if depth != last:
+            blocks.append(dict(cin=cur, cout=cur, scale=0.5, dil=2))
+    return blocks
+
+
+def gn_groups(ch: int) -> int:
+    """unet.py:345-349: start at 32 groups, halve until it divides `ch`."""
+    g = 32
+    while ch % g:
+        g //= 2
+    return g
+
+
+# --------------------------------------------------------------------------
+# layers
+# --------------------------------------------------------------------------
+
+
+def group_norm(x: Tensor, sd: State, prefix: str) -> Tensor:
+    w = sd[prefix + ".weight"]
+    return F.group_norm(x, gn_groups(w.shape[0]), w, sd[prefix + ".bias"], eps=1e-5)
+
+
+def resize(x: Tensor, scale: float) -> Tensor:
+    """unet.py:324-334."""
+    if scale == 1.0:
+        return x
+    if scale < 1.0:
+        return F.avg_pool1d(x, int(round(1 / scale)))
+    return F.interpolate(x, scale_factor=scale)
+
+
+def res_block(x: Tensor, sd: State, p: str, spec: dict, emb: Optional[Tensor]) -> Tensor:
+    """unet.py:307-316 with the module layout of unet.py:265-305."""
+    scale, dil = spec["scale"], spec["dil"]
+    h = F.gelu(group_norm(x, sd, p + ".pre_cond.0.0"))
+    h = resize(h, scale)
+    h = F.conv1d(h, sd[p + ".pre_cond.2.weight"], sd[p + ".pre_cond.2.bias"], padding=1)
+    h = group_norm(h, sd, p + ".pre_cond.3")
+    if emb is not None:
+        ab = F.linear(F.gelu(emb), sd[p + ".cond_layers.1.weight"], sd[p + ".cond_layers.1.bias"])
+        cout = spec["cout"]
+        a, b = ab[:, :cout, None], ab[:, cout:, None]
+        h = h * (a + 1) + b
+    conv2 = p + (".post_cond.2" if (p + ".post_cond.2.weight") in sd else ".post_cond.1")
+    h = F.conv1d(F.gelu(h), sd[conv2 + ".weight"], sd[conv2 + ".bias"], padding=dil, dilation=dil)
+    s = resize(x, scale)
+    if (p + ".skip.1.weight") in sd:
+        s = F.conv1d(s, sd[p + ".skip.1.weight"], sd[p + ".skip.1.bias"])
+    return s + h
+
+
+def time_embedding(ts: Tensor, sd: State, p: str) -> Tensor:
+    """wavegrad.py:359-373."""
+    w = sd[p + ".proj.weight"]
+    half = w.shape[1] // 2
+    freqs = (
+        torch.exp(-math.log(100.0 / 0.1) * torch.arange(0, half, dtype=torch.float32) / (half - 1))
+        * 100.0
+    ).to(ts)
+    args = ts[:, None] * freqs[None]
+    return F.linear(torch.cat([torch.cos(args), torch.sin(args)], dim=-1), w, sd[p + ".proj.bias"])
+
+
+def unet_predictor(
+    sd: State,
+    base: int,
+    x: Tensor,
+    ts: Tensor,
+    cond: Optional[Tensor] = None,
+    labels: Optional[Tensor] = None,
+    prefix: str = "predictor",
+    probe: Optional[Callable[[str, Tensor], None]] = None,
+) -> Tensor:
+    """unet.py:118-163.  `probe(name, tensor)` sees every block output (for bisecting)."""
+    p = prefix
+    has_labels = (p + ".class_embed.weight") in sd
+    has_cond = (p + ".cond_proj.weight") in sd
+    assert (labels is None) == (not has_labels), "must provide labels iff class conditional"
+    assert (cond is None) == (not has_cond), "must provide cond iff conditional"
+    specs = predictor_block_specs(base)
+
+    emb = time_embedding(ts, sd, p + ".time_embed")
+    emb = F.linear(F.gelu(emb), sd[p + ".time_embed_extra.1.weight"], sd[p + ".time_embed_extra.1.bias"])
+    if labels is not None:
+        emb = emb + F.embedding(labels, sd[p + ".class_embed.weight"])
+
+    h = F.conv1d(x, sd[p + ".in_conv.weight"], sd[p + ".in_conv.bias"], padding=1)
+    if cond is not None:
+        c = F.conv1d(cond, sd[p + ".cond_proj.weight"], sd[p + ".cond_proj.bias"], padding=1)
+        h = h + F.interpolate(c, h.shape[-1])
+    if probe:
+        probe("in_conv", h)
+    skips = [h]
+    for i, spec in enumerate(specs["down"]):
+        h = res_block(h, sd, f"{p}.down_blocks.{i}", spec, emb)
+        skips.append(h)
+        if probe:
+            probe(f"down_blocks.{i}", h)
+    for i, spec in enumerate(specs["middle"]):
+        h = res_block(h, sd, f"{p}.middle_blocks.{i}", spec, emb)
+        if probe:
+            probe(f"middle_blocks.{i}", h)
+    for i, spec in enumerate(specs["up"]):
+        if spec["cat"]:
+            h = torch.cat([h, skips.pop()], dim=1)
+        h = res_block(h, sd, f"{p}.up_blocks.{i}", spec, emb)
+        if probe:
+            probe(f"up_blocks.{i}", h)
+    h = F.gelu(group_norm(h, sd, p + ".out.0.0"))
+    return F.conv1d(h, sd[p + ".out.1.weight"], sd[p + ".out.1.bias"], padding=1)
+
+
+def unet_encoder(sd: State, base: int, x: Tensor, prefix: str = "encoder") -> Tensor:
+    """unet.py:229-241."""
+    p = prefix
+    h = F.conv1d(x, sd[p + ".in_conv.weight"], sd[p + ".in_conv.bias"], padding=1)
+    for i, spec in enumerate(encoder_block_specs(base)):
+        h = res_block(h, sd, f"{p}.blocks.{i}", spec, None)
+    h = F.gelu(group_norm(h, sd, p + ".out.0.0"))
+    return F.conv1d(h, sd[p + ".out.1.weight"], sd[p + ".out.1.bias"], padding=1)
+
+
+# --------------------------------------------------------------------------
+# VQ (vq.py:98-143, 199-243)
+# --------------------------------------------------------------------------
+
+
+def vq_distances(dictionary: Tensor, rows: Tensor) -> Tensor:
+    """vq.py:199-221, same evaluation order: ((-2*dots) + |e|^2) + |x|^2."""
+    dict_norms = torch.sum(torch.pow(dictionary, 2), dim=-1)
+    row_norms = torch.sum(torch.pow(rows, 2), dim=-1)
+    lhs = dictionary[None].expand(rows.shape[0], *dictionary.shape)
+    dots = torch.bmm(lhs, rows[:, :, None])[..., 0]
+    return -2 * dots + dict_norms + row_norms[..., None]
+
+
+def vq_encode(dictionary: Tensor, z: Tensor) -> Tensor:
+    """[N,C,T] -> int64 [N,T] code indices (vq.py:127-131, 224-243)."""
+    n, c, t = z.shape
+    rows = z.permute(0, 2, 1).reshape(-1, c)
+    return torch.argmin(vq_distances(dictionary, rows), dim=-1).reshape(n, t)
+
+
+def vq_embed(dictionary: Tensor, idxs: Tensor) -> Tensor:
+    """vq.py:98-110: int [N,T] -> [N,C,T]."""
+    return F.embedding(idxs, dictionary).permute(0, 2, 1).contiguous()
+
+
+# --------------------------------------------------------------------------
+# diffusion (diffusion/schedule.py:15-41, diffusion/diffusion.py:28-133)
+# --------------------------------------------------------------------------
+
+
+def schedule_alpha(name: str, t: Tensor) -> Tensor:
+    if name == "exp":
+        return torch.exp(-(-math.log(1e-5)) * (t ** 2))
+    if name == "cos":
+        return torch.cos(t * math.pi / 2) ** 2
+    raise ValueError(f"unknown schedule: {name}")
+
+
+def _bcast(v: Tensor, like: Tensor) -> Tensor:
+    while v.dim() < like.dim():
+        v = v[:, None]
+    return v.to(like) + torch.zeros_like(like)  # diffusion.py:154-157
+
+
+def ddpm_previous(
+    schedule: str,
+    x_t: Tensor,
+    ts: Tensor,
+    step,
+    eps: Tensor,
+    noise: Tensor,
+    sigma_large: bool = False,
+    constrain: bool = False,
+    cond_fn: Optional[Callable] = None,
+) -> Tensor:
+    """diffusion.py:48-90 (noise is always explicit here)."""
+    a_t = _bcast(schedule_alpha(schedule, ts), x_t)
+    a_prev = _bcast(schedule_alpha(schedule, ts - step), x_t)
+    alphas = a_t / a_prev
+    betas = 1 - alphas
+
+    def eps_to_prev(e):
+        return alphas.rsqrt() * (x_t - betas * (1 - a_t).rsqrt() * e)
+
+    def prev_to_eps(prev):
+        return (-prev * alphas.sqrt() + x_t) * (1 - a_t).sqrt() / betas
+
+    sigmas = betas if sigma_large else betas * (1 - a_prev) / (1 - a_t)
+    if cond_fn is not None:
+        mean = eps_to_prev(eps)
+        mean = mean + sigmas * cond_fn(mean, ts - step)
+        eps = prev_to_eps(mean)
+    if constrain:
+        x0 = (x_t - (1 - a_t).sqrt() * eps) * a_t.rsqrt()
+        x0 = (x0 - x0.mean(dim=-1, keepdim=True)).clamp(-1, 1)
+        eps = (x_t - x0 * a_t.sqrt()) * (1 - a_t).rsqrt()
+    return eps_to_prev(eps) + sigmas.sqrt() * noise
+
+
+def ddpm_sample(
+    schedule: str,
+    x_T: Tensor,
+    predictor: Callable[[Tensor, Tensor], Tensor],
+    steps: int,
+    noises: List[Tensor],
+    sigma_large: bool = False,
+    constrain: bool = False,
+    cond_fn: Optional[Callable] = None,
+    t_map: Optional[Callable[[Tensor], Tensor]] = None,
+    trace: Optional[List[Tensor]] = None,
+) -> Tensor:
+    """diffusion.py:92-133.  `noises[i]` is the N(0,1) draw of iteration i; the last
+    iteration uses zeros regardless (diffusion.py:127)."""
+    x_t = x_T
+    t_list = [(i + 1) / steps for i in range(steps)]
+    for i, t in enumerate(t_list[::-1]):
+        ts = torch.tensor([t] * x_T.shape[0]).to(x_T)
+        t_step = 1 / steps
+        if t_map is not None:
+            t_step = t_map(ts) - t_map(ts - 1 / steps)
+            ts = t_map(ts)
+        with torch.no_grad():
+            eps = predictor(x_t, ts)
+            noise = torch.zeros_like(x_T) if i + 1 == steps else noises[i]
+            x_t = ddpm_previous(
+                schedule, x_t, ts, t_step, eps, noise,
+                sigma_large=sigma_large, constrain=constrain, cond_fn=cond_fn,
+            )
+        if trace is not None:
+            trace.append(x_t)
+    return x_t
+
+
+# --------------------------------------------------------------------------
+# VQ-VAE facade (vq_vae.py:82-145)
+# --------------------------------------------------------------------------
+
+
+def vqvae_encode(sd: State, base: int, inputs: Tensor) -> Tensor:
+    with torch.no_grad():
+        return vq_encode(sd["vq.dictionary"], unet_encoder(sd, base, inputs))
+
+
+def vqvae_decode(
+    sd: State,
+    base: int,
+    schedule: str,
+    codes: Tensor,
+    labels: Optional[Tensor],
+    steps: int,
+    x_T: Tensor,
+    noises: List[Tensor],
+    constrain: bool = False,
+) -> Tensor:
+    cond = vq_embed(sd["vq.dictionary"], codes) if codes.dim() == 2 else codes
+    return ddpm_sample(
+        schedule, x_T,
+        lambda xs, ts: unet_predictor(sd, base, xs, ts, cond=cond, labels=labels),
+        steps, noises, constrain=constrain,
+    )
