@@ -1,0 +1,144 @@
+/*
+ * vqvs.h -- C ABI of the MI355X (gfx950) native sampler library `libvqvs_hip.so`.
+ *
+ * The reference (unixpickle/vq-voice-swap) is pure Python: it has no C / FFI /
+ * operator boundary of its own.  Its boundary for the DDPM sampling hot path is
+ * the Python object surface listed in SURVEY.md section 8(b).  Every entry point
+ * below states the reference interface (file:line under the reference repo) it
+ * stands behind; the Python classes in `vq_voice_swap_amd/` bind them with ctypes
+ * (see INTEGRATION.md for the stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types.  All pointers named `d_*` are
+ *     DEVICE pointers on the model's device; `h_*` are HOST pointers.
+ *   - tensors at the boundary use the reference's layout: float32, NCT
+ *     ([batch][channels][time], time contiguous); indices are int64.
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*;
+ *     NULL = the default stream).  The caller owns all boundary buffers; the
+ *     library owns only the packed weights and a scratch arena per model handle.
+ *   - return value 0 = success, negative = error (vqvs_last_error() describes
+ *     it, thread-local).  Nothing here falls back to a CPU path.
+ *   - a handle is not thread-safe (one scratch arena); different handles are
+ *     independent.  One process per GPU.
+ */
+#ifndef VQVS_H
+#define VQVS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VQVS_OK 0
+#define VQVS_ERR_ARG (-1)     /* bad shape / null pointer / unsupported configuration */
+#define VQVS_ERR_HIP (-2)     /* a HIP runtime call failed */
+#define VQVS_ERR_STATE (-3)   /* handle misuse */
+
+/* network kinds */
+#define VQVS_KIND_PREDICTOR 0 /* UNetPredictor  (reference vq_voice_swap/models/unet.py:16-184) */
+#define VQVS_KIND_ENCODER 1   /* UNetEncoder    (reference unet.py:187-245) */
+#define VQVS_KIND_RESBLOCK 2  /* one ResBlock   (reference unet.py:248-316); unit-test granularity */
+
+/* activation storage / arithmetic */
+#define VQVS_PREC_F32 0  /* fp32 activations; convs as 3-term bf16-split MFMA, fp32 accumulate (~2^-17 rel.) */
+#define VQVS_PREC_BF16 1 /* bf16 activations; bf16 MFMA, fp32 accumulate */
+
+typedef struct vqvs_model vqvs_model;
+
+typedef struct vqvs_cfg {
+  int32_t kind;          /* VQVS_KIND_* */
+  int32_t base_channels; /* multiple of 32 (reference configs: 32, 64) */
+  int32_t in_channels;   /* must be 1 (reference default, unet.py:25) */
+  int32_t out_channels;  /* predictor: 1 or a multiple of 32; encoder: multiple of 32 */
+  int32_t cond_channels; /* 0 = unconditional (unet.py:46-47) */
+  int32_t num_labels;    /* 0 = no class embedding (unet.py:44-45) */
+  int32_t precision;     /* VQVS_PREC_* */
+  int32_t max_batch;     /* scratch arena is sized for this many clips ... */
+  int32_t max_T;         /* ... of this many samples (multiple of 256 for UNets) */
+  int32_t debug_taps;    /* 1 = keep every block output resident for vqvs_debug_read_tap */
+  /* VQVS_KIND_RESBLOCK only: */
+  int32_t rb_cin, rb_cout, rb_resize /*0 none, 1 avg-pool/2, 2 nearest x2*/, rb_dilation, rb_emb_channels /*0 = no FiLM*/;
+  int32_t reserved[5];
+} vqvs_cfg;
+
+/* ---- parameters -----------------------------------------------------------
+ * The library owns the topology.  It enumerates the parameters it needs under
+ * the reference's own state-dict key names (checkpoint format = reference
+ * vq_voice_swap/models/base.py:74-104; key list in SURVEY.md 8(b)), relative to
+ * the module (e.g. "down_blocks.3.pre_cond.2.weight"), so a caller can feed it
+ * from any {"kwargs","state_dict"} checkpoint. */
+int vqvs_param_count(const vqvs_cfg* cfg);
+int vqvs_param_info(const vqvs_cfg* cfg, int index, char* name_out, int name_cap, int64_t shape_out[4], int* ndim_out);
+
+/* Build a model: packs `h_params[i]` (host float32, contiguous, in vqvs_param_info
+ * order) into device-resident MFMA operand layout and allocates the scratch arena.
+ * Replaces nn.Module construction + .to(device): reference diffusion_model.py:14-40,
+ * vq_vae.py:15-32, models/base.py:83-104. */
+int vqvs_model_create(const vqvs_cfg* cfg, const float* const* h_params, int n_params, int device, vqvs_model** out);
+void vqvs_model_destroy(vqvs_model* m);
+/* bytes of device memory held by the handle (weights + arena) */
+int64_t vqvs_model_device_bytes(const vqvs_model* m);
+
+/* ---- UNet forward -----------------------------------------------------------
+ * eps = UNetPredictor.forward(x, ts, cond=, labels=)   reference unet.py:118-163
+ *   d_x     [B,1,T] f32      d_ts [B] f32
+ *   d_cond  [B,cond_channels,T/256] f32 or NULL (must match cfg, unet.py:126-131)
+ *   d_labels[B] int64 or NULL (must match cfg)
+ *   d_out   [B,out_channels,T] f32 */
+int vqvs_unet_forward(vqvs_model* m, const float* d_x, const float* d_ts, const float* d_cond,
+                      const int64_t* d_labels, float* d_out, int B, int T, void* stream);
+
+/* z = UNetEncoder.forward(x)   reference unet.py:229-241
+ *   d_x [B,1,T] f32 -> d_z [B,out_channels,T/256] f32 (NCT) */
+int vqvs_encoder_forward(vqvs_model* m, const float* d_x, float* d_z, int B, int T, void* stream);
+
+/* y = ResBlock.forward(x, emb)   reference unet.py:307-316 (VQVS_KIND_RESBLOCK handles)
+ *   d_x [B,rb_cin,L] f32, d_emb [B,rb_emb_channels] f32 or NULL -> d_y [B,rb_cout,L'] f32 */
+int vqvs_resblock_forward(vqvs_model* m, const float* d_x, const float* d_emb, float* d_y, int B, int L, void* stream);
+
+/* ---- DDPM reverse step --------------------------------------------------------
+ * x_prev = Diffusion.ddpm_previous(x_t, ts, step, eps, noise, sigma_large, constrain)
+ * reference diffusion/diffusion.py:48-90 (without cond_fn; with cond_fn the caller
+ * uses the two half-steps below around its own cond_fn, diffusion.py:80-83).
+ *   d_alpha_t, d_alpha_prev [B] f32: schedule(ts), schedule(ts-step) (schedule.py:30-41)
+ *   d_noise [B,1,T] f32, or NULL to draw N(0,1) in-kernel from Philox4x32-10 keyed by
+ *     (seed, clip_offset + row, step_index) -- independent of how clips are sharded;
+ *     noise_scale 0 reproduces the reference's zero-noise last iteration (diffusion.py:127) */
+#define VQVS_DDPM_SIGMA_LARGE 1u
+#define VQVS_DDPM_CONSTRAIN 2u
+int vqvs_ddpm_step(const float* d_x_t, const float* d_eps, const float* d_noise, const float* d_alpha_t,
+                   const float* d_alpha_prev, float* d_x_prev, int B, int T, uint32_t flags, float noise_scale,
+                   uint64_t seed, uint64_t clip_offset, uint32_t step_index, void* stream);
+/* mean = eps_to_prev(eps)  and  eps' = prev_to_eps(mean + sigma^2 * grad)   (diffusion.py:69-83) */
+int vqvs_ddpm_mean(const float* d_x_t, const float* d_eps, const float* d_alpha_t, const float* d_alpha_prev,
+                   float* d_mean, int B, int T, void* stream);
+int vqvs_ddpm_guided_eps(const float* d_x_t, const float* d_mean, const float* d_grad, const float* d_alpha_t,
+                         const float* d_alpha_prev, float* d_eps_out, int B, int T, uint32_t flags, void* stream);
+/* x_T ~ N(0,1) from the same counter-based generator (replaces torch.randn, sample_diffusion.py:86) */
+int vqvs_randn(float* d_out, int B, int T, uint64_t seed, uint64_t clip_offset, uint32_t stream_id, void* stream);
+
+/* ---- vector quantisation -------------------------------------------------------
+ * idx = argmin_k ((-2 z.e_k) + |e_k|^2) + |z|^2, first index on ties
+ * reference vq.py:112-143, 199-243.   d_z [B,Cd,T1] f32 NCT, d_dict [K,Cd] f32 -> d_idx [B,T1] int64 */
+int vqvs_vq_argmin(const float* d_z, const float* d_dict, int64_t* d_idx, int B, int Cd, int T1, int K, void* stream);
+/* out[b,:,t] = dict[idx[b,t],:]   reference vq.py:98-110 */
+int vqvs_vq_embed(const int64_t* d_idx, const float* d_dict, float* d_out, int B, int Cd, int T1, int K, void* stream);
+
+/* ---- test / profiling hooks ------------------------------------------------------ */
+int vqvs_debug_tap_count(const vqvs_model* m);
+int vqvs_debug_tap_info(const vqvs_model* m, int i, char* name_out, int name_cap, int* channels, int* length_shift);
+/* copies tap i of the LAST forward to host as float32 NCT [B][C][L]; synchronises the device */
+int vqvs_debug_read_tap(vqvs_model* m, int i, int B, int T, float* h_out);
+/* number of kernels one forward enqueues, and the algorithmic activation bytes it moves (SURVEY 8d Model A) */
+int vqvs_forward_kernel_count(const vqvs_model* m);
+int64_t vqvs_forward_model_bytes(const vqvs_model* m, int B, int T);
+int64_t vqvs_forward_flops(const vqvs_model* m, int B, int T);
+
+const char* vqvs_last_error(void);
+const char* vqvs_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VQVS_H */

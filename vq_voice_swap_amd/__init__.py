@@ -1,0 +1,16 @@
+"""
+vq_voice_swap_amd: MI355X (gfx950) native DDPM audio sampler behind the
+DiffusionModel / VQVAE API of unixpickle/vq-voice-swap.  See DESIGN.md.
+"""
+
+from .base import Savable, atomic_save
+from .diffusion import CosSchedule, Diffusion, ExpSchedule, Schedule, make_schedule, randn_clips
+from .diffusion_model import DiffusionModel
+from .unet import ResBlockModule, UNetEncoder, UNetPredictor
+from .vq import VQ
+from .vq_vae import VQVAE
+
+__all__ = [
+    "Savable", "atomic_save", "CosSchedule", "Diffusion", "ExpSchedule", "Schedule", "make_schedule", "randn_clips",
+    "DiffusionModel", "ResBlockModule", "UNetEncoder", "UNetPredictor", "VQ", "VQVAE",
+]

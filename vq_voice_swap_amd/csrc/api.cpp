@@ -1,0 +1,248 @@
+// extern "C" surface of libvqvs_hip.so (declared and documented in include/vqvs.h).
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "net.hpp"
+#include "sampler_kernels.hpp"
+
+namespace vqvs {
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+
+// scratch shared by the handle-less entry points (DDPM step partial sums, VQ code norms)
+struct GlobalScratch {
+  void* p = nullptr;
+  size_t bytes = 0;
+  int device = -1;
+};
+static GlobalScratch g_scratch;
+static std::mutex g_scratch_mu;
+static int scratch_get(size_t bytes, void** out) {
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  int dev = 0;
+  VQVS_HIP(hipGetDevice(&dev));
+  if (g_scratch.p && (g_scratch.device != dev || g_scratch.bytes < bytes)) {
+    VQVS_HIP(hipDeviceSynchronize());
+    VQVS_HIP(hipFree(g_scratch.p));
+    g_scratch = GlobalScratch{};
+  }
+  if (!g_scratch.p) {
+    size_t n = bytes < (size_t)(1 << 20) ? (size_t)(1 << 20) : bytes;
+    VQVS_HIP(hipMalloc(&g_scratch.p, n));
+    g_scratch.bytes = n;
+    g_scratch.device = dev;
+  }
+  *out = g_scratch.p;
+  return 0;
+}
+}  // namespace vqvs
+
+using namespace vqvs;
+
+extern "C" {
+
+const char* vqvs_last_error(void) { return g_err.c_str(); }
+const char* vqvs_version(void) { return "vqvs-hip 0.1 (gfx950)"; }
+
+int vqvs_param_count(const vqvs_cfg* cfg) {
+  if (!cfg) VQVS_FAIL(VQVS_ERR_ARG, "cfg is NULL");
+  std::vector<ParamDef> p;
+  if (int e = enumerate_params(*cfg, p)) return e;
+  return (int)p.size();
+}
+
+int vqvs_param_info(const vqvs_cfg* cfg, int index, char* name_out, int name_cap, int64_t shape_out[4], int* ndim_out) {
+  if (!cfg) VQVS_FAIL(VQVS_ERR_ARG, "cfg is NULL");
+  std::vector<ParamDef> p;
+  if (int e = enumerate_params(*cfg, p)) return e;
+  if (index < 0 || index >= (int)p.size()) VQVS_FAIL(VQVS_ERR_ARG, "param index %d out of range", index);
+  const ParamDef& d = p[index];
+  if (name_out && name_cap > 0) {
+    strncpy(name_out, d.name.c_str(), name_cap - 1);
+    name_out[name_cap - 1] = 0;
+  }
+  if (shape_out)
+    for (int i = 0; i < 4; ++i) shape_out[i] = i < (int)d.shape.size() ? d.shape[i] : 1;
+  if (ndim_out) *ndim_out = (int)d.shape.size();
+  return 0;
+}
+
+int vqvs_model_create(const vqvs_cfg* cfg, const float* const* h_params, int n_params, int device, vqvs_model** out) {
+  if (!cfg || !h_params || !out) VQVS_FAIL(VQVS_ERR_ARG, "NULL argument");
+  *out = nullptr;
+  std::vector<ParamDef> p;
+  if (int e = enumerate_params(*cfg, p)) return e;
+  if (n_params != (int)p.size()) VQVS_FAIL(VQVS_ERR_ARG, "expected %d parameters, got %d", (int)p.size(), n_params);
+  for (int i = 0; i < n_params; ++i)
+    if (!h_params[i]) VQVS_FAIL(VQVS_ERR_ARG, "parameter %d (%s) is NULL", i, p[i].name.c_str());
+  int ndev = 0;
+  VQVS_HIP(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) VQVS_FAIL(VQVS_ERR_ARG, "device %d not present (%d visible)", device, ndev);
+  VQVS_HIP(hipSetDevice(device));
+  vqvs_model* m = new vqvs_model();
+  m->cfg = *cfg;
+  m->device = device;
+  if (int e = build_model(m, h_params)) {
+    vqvs_model_destroy(m);
+    return e;
+  }
+  *out = m;
+  return 0;
+}
+
+void vqvs_model_destroy(vqvs_model* m) {
+  if (!m) return;
+  if (m->d_weights) (void)hipFree(m->d_weights);
+  if (m->d_arena) (void)hipFree(m->d_arena);
+  delete m;
+}
+
+int64_t vqvs_model_device_bytes(const vqvs_model* m) { return m ? (int64_t)(m->weights_bytes + m->arena_bytes) : 0; }
+
+static int check_run(vqvs_model* m, int kind, int B, int L) {
+  if (!m) VQVS_FAIL(VQVS_ERR_ARG, "model is NULL");
+  if (m->cfg.kind != kind) VQVS_FAIL(VQVS_ERR_STATE, "handle kind %d used as kind %d", m->cfg.kind, kind);
+  if (B < 1 || B > m->cfg.max_batch) VQVS_FAIL(VQVS_ERR_ARG, "batch %d outside 1..%d", B, m->cfg.max_batch);
+  if (L < 1 || L > m->cfg.max_T) VQVS_FAIL(VQVS_ERR_ARG, "length %d outside 1..%d", L, m->cfg.max_T);
+  if (kind != VQVS_KIND_RESBLOCK && (L % 256)) VQVS_FAIL(VQVS_ERR_ARG, "T=%d is not a multiple of the UNet downsample rate 256", L);
+  if (kind == VQVS_KIND_RESBLOCK && m->cfg.rb_resize == RESIZE_AVG2 && (L % 2)) VQVS_FAIL(VQVS_ERR_ARG, "avg-pool resblock needs even L");
+  return 0;
+}
+
+int vqvs_unet_forward(vqvs_model* m, const float* d_x, const float* d_ts, const float* d_cond, const int64_t* d_labels, float* d_out,
+                      int B, int T, void* stream) {
+  if (int e = check_run(m, VQVS_KIND_PREDICTOR, B, T)) return e;
+  if (!d_x || !d_ts || !d_out) VQVS_FAIL(VQVS_ERR_ARG, "x, ts and out must be non-NULL");
+  // reference unet.py:126-131
+  if ((d_labels == nullptr) != (m->cfg.num_labels == 0)) VQVS_FAIL(VQVS_ERR_ARG, "must provide labels if and only if model is class conditional");
+  if ((d_cond == nullptr) != (m->cfg.cond_channels == 0)) VQVS_FAIL(VQVS_ERR_ARG, "must provide cond sequence if and only if model is conditional");
+  RunCtx c;
+  c.B = B;
+  c.Lbase = T;
+  c.x = d_x;
+  c.ts = d_ts;
+  c.cond = d_cond;
+  c.labels = d_labels;
+  c.out = d_out;
+  c.st = reinterpret_cast<hipStream_t>(stream);
+  return run_model(m, c);
+}
+
+int vqvs_encoder_forward(vqvs_model* m, const float* d_x, float* d_z, int B, int T, void* stream) {
+  if (int e = check_run(m, VQVS_KIND_ENCODER, B, T)) return e;
+  if (!d_x || !d_z) VQVS_FAIL(VQVS_ERR_ARG, "x and z must be non-NULL");
+  RunCtx c;
+  c.B = B;
+  c.Lbase = T;
+  c.x = d_x;
+  c.out = d_z;
+  c.st = reinterpret_cast<hipStream_t>(stream);
+  return run_model(m, c);
+}
+
+int vqvs_resblock_forward(vqvs_model* m, const float* d_x, const float* d_emb, float* d_y, int B, int L, void* stream) {
+  if (int e = check_run(m, VQVS_KIND_RESBLOCK, B, L)) return e;
+  if (!d_x || !d_y) VQVS_FAIL(VQVS_ERR_ARG, "x and y must be non-NULL");
+  if ((d_emb == nullptr) != (m->cfg.rb_emb_channels == 0)) VQVS_FAIL(VQVS_ERR_ARG, "emb must be given iff the block has cond_layers");
+  RunCtx c;
+  c.B = B;
+  c.Lbase = L;
+  c.x = d_x;
+  c.emb = d_emb;
+  c.out = d_y;
+  c.st = reinterpret_cast<hipStream_t>(stream);
+  return run_model(m, c);
+}
+
+int vqvs_ddpm_step(const float* d_x_t, const float* d_eps, const float* d_noise, const float* d_alpha_t, const float* d_alpha_prev,
+                   float* d_x_prev, int B, int T, uint32_t flags, float noise_scale, uint64_t seed, uint64_t clip_offset,
+                   uint32_t step_index, void* stream) {
+  if (!d_x_t || !d_eps || !d_alpha_t || !d_alpha_prev || !d_x_prev) VQVS_FAIL(VQVS_ERR_ARG, "NULL argument");
+  if (B < 1 || T < 1) VQVS_FAIL(VQVS_ERR_ARG, "bad shape B=%d T=%d", B, T);
+  void* scratch = nullptr;
+  if (flags & VQVS_DDPM_CONSTRAIN)
+    if (int e = scratch_get((size_t)ddpm_scratch_doubles(B, T) * 8, &scratch)) return e;
+  return run_ddpm_step(d_x_t, d_eps, d_noise, d_alpha_t, d_alpha_prev, d_x_prev, reinterpret_cast<double*>(scratch), B, T, flags,
+                       noise_scale, seed, clip_offset, step_index, reinterpret_cast<hipStream_t>(stream));
+}
+
+int vqvs_ddpm_mean(const float* d_x_t, const float* d_eps, const float* d_alpha_t, const float* d_alpha_prev, float* d_mean, int B, int T,
+                   void* stream) {
+  if (!d_x_t || !d_eps || !d_alpha_t || !d_alpha_prev || !d_mean) VQVS_FAIL(VQVS_ERR_ARG, "NULL argument");
+  return run_ddpm_mean(d_x_t, d_eps, d_alpha_t, d_alpha_prev, d_mean, B, T, reinterpret_cast<hipStream_t>(stream));
+}
+
+int vqvs_ddpm_guided_eps(const float* d_x_t, const float* d_mean, const float* d_grad, const float* d_alpha_t, const float* d_alpha_prev,
+                         float* d_eps_out, int B, int T, uint32_t flags, void* stream) {
+  if (!d_x_t || !d_mean || !d_grad || !d_alpha_t || !d_alpha_prev || !d_eps_out) VQVS_FAIL(VQVS_ERR_ARG, "NULL argument");
+  return run_ddpm_guided_eps(d_x_t, d_mean, d_grad, d_alpha_t, d_alpha_prev, d_eps_out, B, T, flags, reinterpret_cast<hipStream_t>(stream));
+}
+
+int vqvs_randn(float* d_out, int B, int T, uint64_t seed, uint64_t clip_offset, uint32_t stream_id, void* stream) {
+  if (!d_out || B < 1 || T < 1) VQVS_FAIL(VQVS_ERR_ARG, "bad argument");
+  return run_randn(d_out, B, T, seed, clip_offset, stream_id, reinterpret_cast<hipStream_t>(stream));
+}
+
+int vqvs_vq_argmin(const float* d_z, const float* d_dict, int64_t* d_idx, int B, int Cd, int T1, int K, void* stream) {
+  if (!d_z || !d_dict || !d_idx) VQVS_FAIL(VQVS_ERR_ARG, "NULL argument");
+  if (B < 1 || Cd < 1 || T1 < 1 || K < 1) VQVS_FAIL(VQVS_ERR_ARG, "bad shape");
+  if (Cd % 4) VQVS_FAIL(VQVS_ERR_ARG, "Cd must be a multiple of 4 (got %d)", Cd);
+  void* scratch = nullptr;
+  if (int e = scratch_get((size_t)K * 4, &scratch)) return e;
+  return run_vq_argmin(d_z, d_dict, reinterpret_cast<float*>(scratch), d_idx, B, Cd, T1, K, reinterpret_cast<hipStream_t>(stream));
+}
+
+int vqvs_vq_embed(const int64_t* d_idx, const float* d_dict, float* d_out, int B, int Cd, int T1, int K, void* stream) {
+  if (!d_idx || !d_dict || !d_out) VQVS_FAIL(VQVS_ERR_ARG, "NULL argument");
+  return run_vq_embed(d_idx, d_dict, d_out, B, Cd, T1, K, reinterpret_cast<hipStream_t>(stream));
+}
+
+int vqvs_debug_tap_count(const vqvs_model* m) { return m ? (int)m->taps.size() : 0; }
+
+int vqvs_debug_tap_info(const vqvs_model* m, int i, char* name_out, int name_cap, int* channels, int* length_shift) {
+  if (!m || i < 0 || i >= (int)m->taps.size()) VQVS_FAIL(VQVS_ERR_ARG, "bad tap index");
+  if (name_out && name_cap > 0) {
+    strncpy(name_out, m->taps[i].name.c_str(), name_cap - 1);
+    name_out[name_cap - 1] = 0;
+  }
+  if (channels) *channels = m->taps[i].t.C;
+  if (length_shift) *length_shift = m->taps[i].t.lshift;
+  return 0;
+}
+
+int vqvs_debug_read_tap(vqvs_model* m, int i, int B, int T, float* h_out) {
+  if (!m || i < 0 || i >= (int)m->taps.size() || !h_out) VQVS_FAIL(VQVS_ERR_ARG, "bad argument");
+  if (!m->cfg.debug_taps) VQVS_FAIL(VQVS_ERR_STATE, "model was not created with debug_taps=1");
+  const TensorH& t = m->taps[i].t;
+  const int L = t.lshift >= 0 ? (T >> t.lshift) : (T << -t.lshift);
+  const size_t n = (size_t)B * t.C * L;
+  float* d_tmp = nullptr;
+  VQVS_HIP(hipSetDevice(m->device));
+  VQVS_HIP(hipMalloc(reinterpret_cast<void**>(&d_tmp), n * 4));
+  int e = launch_ntc_to_nct(m->d_arena + t.off, d_tmp, B, t.C, L, t.f32 ? 0 : m->cfg.precision, nullptr);
+  if (!e) {
+    hipError_t he = hipMemcpy(h_out, d_tmp, n * 4, hipMemcpyDeviceToHost);
+    if (he != hipSuccess) {
+      set_error(std::string("hipMemcpy failed: ") + hipGetErrorString(he));
+      e = VQVS_ERR_HIP;
+    }
+  }
+  (void)hipFree(d_tmp);
+  return e;
+}
+
+int vqvs_forward_kernel_count(const vqvs_model* m) { return m ? (int)m->ops.size() : 0; }
+
+int64_t vqvs_forward_model_bytes(const vqvs_model* m, int B, int T) {
+  if (!m) return 0;
+  const double es = m->cfg.precision == VQVS_PREC_F32 ? 4.0 : 2.0;
+  return (int64_t)((m->cost.elems_T * es + m->cost.bytes_f32) * (double)T * (double)B);
+}
+
+int64_t vqvs_forward_flops(const vqvs_model* m, int B, int T) {
+  if (!m) return 0;
+  return (int64_t)(m->cost.flops * (double)T * (double)B);
+}
+
+}  // extern "C"

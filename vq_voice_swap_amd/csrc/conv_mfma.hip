@@ -1,0 +1,287 @@
+// Fused GroupNorm/FiLM/GELU/resize -> Conv1d (k=3 dilated | k=1) -> skip/bias/statistics,
+// as an implicit GEMM on the gfx950 matrix cores.  See kernels.hpp for the operator contract
+// and DESIGN.md section 3 for the tiling.
+//
+//   workgroup  = 256 threads = 4 waves, output tile 256 time rows x CT channels (CT = 32*WN)
+//   wave       = 64 rows x CT channels = 2 x WN tiles of v_mfma_f32_32x32x16_bf16
+//   GEMM roles : A = activations (M = time), B = weights (N = output channel), so an
+//                accumulator lane owns ONE output channel -> channel statistics are in-lane.
+//   K loop     : segment -> chunk of 32 input channels -> tap -> 2 k-steps of 16.
+//                One staged activation chunk (rows t0-d .. t0+255+d, 32 channels, prologue
+//                applied once) serves all three taps: the taps differ only in the LDS row a
+//                lane reads.
+//   LDS rows are 64 B of bf16 padded to 80 B: a ds_read_b128 lane group then touches 16
+//                distinct 16-byte slots (5*r mod 16 is a bijection) -> conflict free.
+//   VQVS_PREC_F32: operands are split x = hi + lo in bf16 and the product is evaluated as
+//                hi*hi + lo*hi + hi*lo with fp32 accumulation (drops only lo*lo ~ 2^-18).
+#include "kernels.hpp"
+
+namespace vqvs {
+
+namespace {
+
+constexpr int TT = 256;          // time rows per workgroup (== STAT_TILE)
+constexpr int ROWB = 80;         // LDS bytes per 32-channel row (64 data + 16 pad)
+constexpr int ACT_ROWS = TT + 64;  // halo for dilation <= 32
+constexpr int ACT_BYTES = ACT_ROWS * ROWB;
+
+template <bool X3>
+__device__ __forceinline__ void put_row(char* act_hi, char* act_lo, int off, f32x8 v) {
+  if constexpr (X3) {
+    bf16x8 hi, lo;
+    split_bf16(v, hi, lo);
+    *reinterpret_cast<bf16x8*>(act_hi + off) = hi;
+    *reinterpret_cast<bf16x8*>(act_lo + off) = lo;
+  } else {
+    *reinterpret_cast<bf16x8*>(act_hi + off) = __builtin_convertvector(v, bf16x8);
+  }
+}
+
+__device__ __forceinline__ f32x8 affine_gelu(f32x8 v, const f32x8& sc, const f32x8& sh) {
+  f32x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = gelu_f(fmaf(v[j], sc[j], sh[j]));
+  return r;
+}
+
+template <typename T, bool X3, int WN>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
+  constexpr int WM = 2;
+  constexpr int CT = WN * 32;
+  constexpr int W_BYTES = 3 * CT * ROWB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const act_hi = smem;
+  char* const act_lo = smem + ACT_BYTES;  // X3 only
+  char* const w_hi = smem + (X3 ? 2 : 1) * ACT_BYTES;
+  char* const w_lo = w_hi + W_BYTES;  // X3 only
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int b = blockIdx.z;
+  const int co0 = blockIdx.y * CT;
+  const int t0 = blockIdx.x * TT;
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int l31 = lane & 31;
+  const int khalf = (lane >> 5) * 16;  // byte offset of this lane's 8-wide k slice within a 16-wide k-step
+
+  for (int s = 0; s < a.nseg; ++s) {
+    const SegDesc& sg = a.seg[s];
+    const int ntaps = sg.ntaps;
+    const int d = (ntaps == 3) ? sg.dil : 0;
+    const int nchunks = sg.C >> 5;
+    const bool up = sg.resize == RESIZE_UP2;
+    const bool avg = sg.resize == RESIZE_AVG2;
+    const int nrows = up ? (TT / 2 + 2) : (TT + 2 * d);
+    const int base_time = up ? ((t0 >> 1) - 1) : (t0 - d);
+    const int row_bound = avg ? a.Lout : sg.Lsrc;  // valid range of the staged row's time index
+    const T* const src_b = reinterpret_cast<const T*>(sg.src) + (size_t)b * sg.Lsrc * sg.Csrc;
+    const bool xform = sg.ss != nullptr;
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+      __syncthreads();  // all waves finished reading the previous chunk
+      // ---------------- stage activations (prologue fused) ----------------
+      {
+        const int oct = tid & 3;
+        const int cl = ch * 32 + oct * 8;
+        f32x8 sc, sh;
+        if (xform) {
+          const float2* p = sg.ss + (size_t)b * sg.ss_stride + sg.ss_c0 + cl;
+#pragma unroll
+          for (int j = 0; j < 8; j += 2) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(p + j);
+            sc[j] = q[0]; sh[j] = q[1]; sc[j + 1] = q[2]; sh[j + 1] = q[3];
+          }
+        }
+        const T* const src_c = src_b + sg.c0 + cl;
+        for (int r = tid >> 2; r < nrows; r += 64) {
+          const int tm = base_time + r;
+          f32x8 v = f32x8_zero();
+          if (tm >= 0 && tm < row_bound) {
+            if (avg) {
+              const T* p = src_c + (size_t)(2 * tm) * sg.Csrc;
+              f32x8 v0 = Elem<T>::load8(p);
+              f32x8 v1 = Elem<T>::load8(p + sg.Csrc);
+              if (xform) { v0 = affine_gelu(v0, sc, sh); v1 = affine_gelu(v1, sc, sh); }
+              v = (v0 + v1) * 0.5f;
+            } else {
+              v = Elem<T>::load8(src_c + (size_t)tm * sg.Csrc);
+              if (xform) v = affine_gelu(v, sc, sh);
+            }
+          }
+          put_row<X3>(act_hi, act_lo, r * ROWB + oct * 16, v);
+        }
+      }
+      // ---------------- stage weights ----------------
+      {
+        const int nvec = ntaps * CT * 4;  // 16-byte pieces
+        for (int i = tid; i < nvec; i += 256) {
+          const int row = i >> 2, q = i & 3;
+          const int tap = row / CT, col = row - tap * CT;
+          const long long e = sg.w_off + ((long long)((ch * ntaps + tap) * a.Cout + co0 + col)) * 32 + q * 8;
+          *reinterpret_cast<bf16x8*>(w_hi + row * ROWB + q * 16) = *reinterpret_cast<const bf16x8*>(a.w_hi + e);
+          if constexpr (X3)
+            *reinterpret_cast<bf16x8*>(w_lo + row * ROWB + q * 16) = *reinterpret_cast<const bf16x8*>(a.w_lo + e);
+        }
+      }
+      __syncthreads();
+      // ---------------- MFMA ----------------
+      for (int k = 0; k < ntaps; ++k) {
+        const int toff = (ntaps == 3) ? (k - 1) * d : 0;
+        int arow[WM];
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt) {
+          const int tl = wave * (WM * 32) + mt * 32 + l31;
+          arow[mt] = up ? (((tl + toff) >> 1) + 1) : (tl + toff + d);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int kb = ks * 32 + khalf;
+          bf16x8 ah[WM], al[WM], bh[WN], bl[WN];
+#pragma unroll
+          for (int mt = 0; mt < WM; ++mt) {
+            ah[mt] = *reinterpret_cast<const bf16x8*>(act_hi + arow[mt] * ROWB + kb);
+            if constexpr (X3) al[mt] = *reinterpret_cast<const bf16x8*>(act_lo + arow[mt] * ROWB + kb);
+          }
+#pragma unroll
+          for (int nt = 0; nt < WN; ++nt) {
+            const int wrow = k * CT + nt * 32 + l31;
+            bh[nt] = *reinterpret_cast<const bf16x8*>(w_hi + wrow * ROWB + kb);
+            if constexpr (X3) bl[nt] = *reinterpret_cast<const bf16x8*>(w_lo + wrow * ROWB + kb);
+          }
+#pragma unroll
+          for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt) {
+              if constexpr (X3) {
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+              }
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+            }
+        }
+      }
+    }
+  }
+
+  // ------------------------------ epilogue ------------------------------
+  // accumulators -> LDS tile [256][CT+4] f32 -> whole-row reads: bias, skip, statistics, store.
+  constexpr int OS = CT + 4;
+  float* const ost = reinterpret_cast<float*>(smem);
+  __syncthreads();
+#pragma unroll
+  for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wave * (WM * 32) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        ost[row * OS + nt * 32 + l31] = acc[mt][nt][r];
+      }
+  __syncthreads();
+
+  constexpr int OPR = CT / 8;     // 8-channel octets per row
+  constexpr int RPP = 256 / OPR;  // rows per pass
+  const int oct = tid % OPR;
+  const int r0 = tid / OPR;
+  const int cg = co0 + oct * 8;
+  const f32x8 bias8 = Elem<float>::load8(a.bias + cg);
+  f32x8 s1 = f32x8_zero(), s2 = f32x8_zero();
+  const T* const skip_b = a.skip ? reinterpret_cast<const T*>(a.skip) + (size_t)b * a.skip_L * a.skip_C + cg : nullptr;
+  for (int r = r0; r < TT; r += RPP) {
+    const int tm = t0 + r;
+    if (tm >= a.Lout) break;
+    const float* o = ost + r * OS + oct * 8;
+    f32x8 v = Elem<float>::load8(o) + bias8;
+    if (skip_b) {
+      if (a.skip_resize == RESIZE_NONE) {
+        v += Elem<T>::load8(skip_b + (size_t)tm * a.skip_C);
+      } else if (a.skip_resize == RESIZE_AVG2) {
+        const T* p = skip_b + (size_t)(2 * tm) * a.skip_C;
+        v += (Elem<T>::load8(p) + Elem<T>::load8(p + a.skip_C)) * 0.5f;
+      } else {
+        v += Elem<T>::load8(skip_b + (size_t)(tm >> 1) * a.skip_C);
+      }
+    }
+    s1 += v;
+    s2 += v * v;
+    const size_t oidx = ((size_t)b * a.Lout + tm) * a.Cout + cg;
+    if (a.out_f32)
+      Elem<float>::store8(reinterpret_cast<float*>(a.out) + oidx, v);
+    else
+      Elem<T>::store8(reinterpret_cast<T*>(a.out) + oidx, v);
+  }
+  if (a.stats) {
+    __syncthreads();
+    float* const red = reinterpret_cast<float*>(smem);  // [RPP][CT][2]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      red[(r0 * CT + oct * 8 + j) * 2 + 0] = s1[j];
+      red[(r0 * CT + oct * 8 + j) * 2 + 1] = s2[j];
+    }
+    __syncthreads();
+    if (tid < CT) {
+      float t1 = 0.f, t2 = 0.f;
+      for (int g = 0; g < RPP; ++g) {  // fixed order: deterministic
+        t1 += red[(g * CT + tid) * 2 + 0];
+        t2 += red[(g * CT + tid) * 2 + 1];
+      }
+      float* o = a.stats + (((size_t)b * a.ntiles + blockIdx.x) * a.Cout + co0 + tid) * 2;
+      o[0] = t1;
+      o[1] = t2;
+    }
+  }
+}
+
+template <bool X3, int WN>
+constexpr int lds_bytes() {
+  constexpr int CT = WN * 32;
+  constexpr int stage = (X3 ? 2 : 1) * (ACT_BYTES + 3 * CT * ROWB);
+  constexpr int ost = TT * (CT + 4) * 4;
+  return stage > ost ? stage : ost;
+}
+
+template <typename T, bool X3, int WN>
+int launch_t(const ConvArgs& a, int B, hipStream_t st) {
+  constexpr int LDS = lds_bytes<X3, WN>();
+  static bool attr_done = false;
+  if (!attr_done) {
+    VQVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<T, X3, WN>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_done = true;
+  }
+  dim3 grid((a.Lout + TT - 1) / TT, a.Cout / (WN * 32), B);
+  hipLaunchKernelGGL((conv_mfma_kernel<T, X3, WN>), grid, dim3(256), LDS, st, a);
+  VQVS_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+int conv_lds_bytes(int precision, int wn) {
+  if (precision == 0) return wn == 2 ? lds_bytes<true, 2>() : lds_bytes<true, 1>();
+  return wn == 2 ? lds_bytes<false, 2>() : lds_bytes<false, 1>();
+}
+
+int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st) {
+  if (a.Cout % 32 != 0 || a.nseg < 1 || a.nseg > 3) VQVS_FAIL(-1, "conv: unsupported shape Cout=%d nseg=%d", a.Cout, a.nseg);
+  for (int s = 0; s < a.nseg; ++s) {
+    const SegDesc& g = a.seg[s];
+    if (g.C % 32 != 0 || (g.ntaps != 1 && g.ntaps != 3) || g.dil > 32 || g.dil < 1)
+      VQVS_FAIL(-1, "conv: unsupported segment C=%d taps=%d dil=%d", g.C, g.ntaps, g.dil);
+    if (g.resize == RESIZE_UP2 && g.ntaps == 3 && g.dil != 1) VQVS_FAIL(-1, "conv: upsample needs dilation 1");
+  }
+  const bool wide = (a.Cout % 64) == 0;
+  if (precision == 0) return wide ? launch_t<float, true, 2>(a, B, st) : launch_t<float, true, 1>(a, B, st);
+  return wide ? launch_t<bf16_t, false, 2>(a, B, st) : launch_t<bf16_t, false, 1>(a, B, st);
+}
+
+}  // namespace vqvs

@@ -1,0 +1,136 @@
+// Kernel argument blocks + host launchers (definitions in *.hip).
+//
+// Activation layout inside the library is channels-last: [clip][time][channel]
+// ("NTC"), element type T = float (VQVS_PREC_F32) or bf16 (VQVS_PREC_BF16).  A time
+// row of C channels is contiguous, which is what an MFMA operand fragment wants
+// (8 consecutive k = 8 consecutive channels = one 16-byte LDS read) and what makes
+// every HBM access of a wave a run of whole rows.
+#pragma once
+
+#include "common.hpp"
+
+namespace vqvs {
+
+// ----------------------------------------------------------------------------------
+// Fused 1-D convolution as an implicit GEMM on MFMA.
+//
+//   out[b][t][co] = bias[co] + sum over segments s, taps k, channels c of
+//                   W_s[co][c][k] * in_s[b][t + (k-1)*dil_s][c]            (zero padded)
+//                   (+ identity skip: resize(skip)[b][t][co])
+//
+// A *segment* is one K-range of the GEMM: a source tensor read through an optional
+// fused prologue.  This covers, in one kernel, everything a reference ResBlock does
+// around its two convolutions (reference vq_voice_swap/models/unet.py:280-316):
+//   xform   : y = gelu(x*scale + shift) with per-(clip,channel) scale/shift, i.e.
+//             GroupNorm (unet.py:345-349) [+ FiLM h*(a+1)+b, unet.py:311-314] + GELU
+//   resize  : avg_pool1d(.,2) or nearest x2 applied between the activation and the conv
+//             (unet.py:280-285, 324-334), evaluated while staging rows into LDS
+//   concat  : torch.cat([h, skip], 1) (unet.py:156) = two 3-tap segments
+//   1x1 skip: skip conv (unet.py:265-267) = extra 1-tap raw segments of the same GEMM
+// Epilogue: bias, identity skip (with the same resize), per-(clip,tile,channel) sum and
+// sum-of-squares of the result (feeds the next GroupNorm), store.
+// ----------------------------------------------------------------------------------
+enum { RESIZE_NONE = 0, RESIZE_AVG2 = 1, RESIZE_UP2 = 2 };
+
+struct SegDesc {
+  const void* src;   // [B][Lsrc][Csrc] of T
+  const float2* ss;  // [B][ss_stride] (scale, shift) or nullptr = raw segment (no affine, no GELU)
+  long long w_off;   // element offset of this segment in the packed weights
+  int Csrc;          // channels per row of the source tensor
+  int c0;            // first source channel used
+  int C;             // channels used (multiple of 32)
+  int Lsrc;          // rows per clip in the source
+  int ntaps;         // 3 (dilated) or 1
+  int dil;
+  int resize;        // RESIZE_*
+  int ss_stride, ss_c0;
+};
+
+struct ConvArgs {
+  SegDesc seg[3];
+  int nseg;
+  const bf16_t* w_hi;  // packed [segment][chunk of 32 ci][tap][Cout][32] (hi part of the bf16 split)
+  const bf16_t* w_lo;  // lo part (VQVS_PREC_F32 only)
+  const float* bias;   // [Cout]
+  int Cout, Lout;
+  const void* skip;  // identity-skip source [B][skip_L][skip_C] of T, or nullptr
+  int skip_C, skip_L, skip_resize;
+  void* out;       // [B][Lout][Cout] of T (or float if out_f32)
+  int out_f32;
+  float* stats;  // [B][ntiles][Cout][2] or nullptr
+  int ntiles;
+};
+
+int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st);
+int conv_lds_bytes(int precision, int wn);
+
+// ----------------------------------------------------------------------------------
+// small kernels
+// ----------------------------------------------------------------------------------
+struct InConvArgs {  // Conv1d(1 -> C, k=3, pad=1) (+ nearest-upsampled cond projection), unet.py:137-139
+  const float* x;    // [B][T]
+  const float* w;    // [C][3]
+  const float* bias; // [C]
+  const void* condp; // [B][T/cond_rate][C] of T or nullptr
+  int cond_rate;
+  void* out;         // [B][T][C] of T
+  float* stats;      // [B][ntiles][C][2]
+  int C, T, ntiles;
+};
+int launch_in_conv(const InConvArgs& a, int B, int precision, hipStream_t st);
+
+struct OutConvArgs {  // GroupNorm+GELU then Conv1d(C -> 1, k=3, pad=1), unet.py:113-116, 162
+  const void* in;     // [B][L][C] of T
+  const float2* ss;   // [B][C]
+  const float* w;     // [3][C] (tap-major)
+  float bias;
+  float* out;         // [B][L] f32
+  int C, L;
+};
+int launch_out_conv(const OutConvArgs& a, int B, int precision, hipStream_t st);
+
+struct GnSrc {
+  const float* partials;  // [B][ntiles][C][2]
+  int ntiles, C;
+};
+struct GnArgs {  // per-(clip,channel) scale/shift of GroupNorm [+FiLM]; nn.GroupNorm eps=1e-5, unet.py:345-349
+  GnSrc src[2];
+  int nsrc, Ctot, groups;
+  double inv_count;    // 1 / (channels_per_group * L)
+  const float* gamma;  // [Ctot]
+  const float* beta;   // [Ctot]
+  const float* film;   // [B][film_stride] rows (a | b) at film_off, or nullptr   (unet.py:311-314)
+  int film_stride, film_off;
+  float2* ss;          // out [B][Ctot]
+};
+int launch_gn_prepare(const GnArgs& a, int B, hipStream_t st);
+
+struct TimeEmbedArgs {  // wavegrad.py:359-373 + unet.py:41-45, 133-135
+  const float* ts;      // [B]
+  const float* freqs;   // [E/2]
+  const float *w1, *b1; // [E][E], [E]   time_embed.proj
+  const float *w2, *b2; // time_embed_extra.1
+  const float* class_embed;  // [num_labels][E] or nullptr
+  const int64_t* labels;     // [B] or nullptr
+  int num_labels;
+  float* emb;   // [B][E]
+  float* gemb;  // [B][E] = gelu(emb), input of every block's cond_layers (unet.py:273-278)
+  int E;
+};
+int launch_time_embed(const TimeEmbedArgs& a, int B, hipStream_t st);
+int launch_gelu_rows(const float* in, float* out, int n, hipStream_t st);
+
+struct FilmArgs {  // all blocks' cond_layers Linear at once: film[b][r] = bias[r] + W[r] . gemb[b]
+  const float* gemb;  // [B][E]
+  const float* w;     // [R][E]
+  const float* bias;  // [R]
+  float* film;        // [B][R]
+  int E, R;
+};
+int launch_film(const FilmArgs& a, int B, hipStream_t st);
+
+// layout changes at the library boundary (reference tensors are NCT float32)
+int launch_nct_to_ntc(const float* in, void* out, float* stats, int B, int C, int L, int ntiles, int precision, hipStream_t st);
+int launch_ntc_to_nct(const void* in, float* out, int B, int C, int L, int in_precision, hipStream_t st);
+
+}  // namespace vqvs

@@ -1,0 +1,419 @@
+// Bandwidth-bound and tiny kernels around the MFMA convolutions: the 1->C input conv, the
+// C->1 output conv, GroupNorm/FiLM coefficient preparation, the timestep embedding, and the
+// NCT<->NTC layout changes at the library boundary.
+#include "kernels.hpp"
+
+namespace vqvs {
+
+namespace {
+
+// ------------------------------------------------------------------------------------
+// in_conv: out[b][t][c] = bias[c] + sum_k w[c][k] x[b][t+k-1]  (+ condp[b][t/rate][c])
+// One thread = one time row x 8 channels; a workgroup = 256 rows = one statistics tile.
+// Pure write-bound: 4 B read, C*sizeof(T) B written per row.
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void in_conv_kernel(const InConvArgs a) {
+  __shared__ float red[256 * 8 * 2];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * STAT_TILE;
+  const int opr = a.C >> 3;      // octets per row
+  const int rpp = 256 / opr;     // rows per pass
+  const int oct = tid % opr;
+  const int r0 = tid / opr;
+  const int c = oct * 8;
+  float w0[8], w1[8], w2[8], bs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    w0[j] = a.w[(c + j) * 3 + 0];
+    w1[j] = a.w[(c + j) * 3 + 1];
+    w2[j] = a.w[(c + j) * 3 + 2];
+    bs[j] = a.bias[c + j];
+  }
+  const float* xb = a.x + (size_t)b * a.T;
+  f32x8 s1 = f32x8_zero(), s2 = f32x8_zero();
+  const bool active = r0 < rpp && oct < opr;
+  if (active) {
+    for (int r = r0; r < STAT_TILE; r += rpp) {
+      const int t = t0 + r;
+      if (t >= a.T) break;
+      const float xm = t > 0 ? xb[t - 1] : 0.f;
+      const float x0 = xb[t];
+      const float xp = t + 1 < a.T ? xb[t + 1] : 0.f;
+      f32x8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = fmaf(w2[j], xp, fmaf(w1[j], x0, fmaf(w0[j], xm, bs[j])));
+      if (a.condp) {
+        const T* cp = reinterpret_cast<const T*>(a.condp) + ((size_t)b * (a.T / a.cond_rate) + t / a.cond_rate) * a.C + c;
+        v += Elem<T>::load8(cp);
+      }
+      s1 += v;
+      s2 += v * v;
+      Elem<T>::store8(reinterpret_cast<T*>(a.out) + ((size_t)b * a.T + t) * a.C + c, v);
+    }
+  }
+  // deterministic tile statistics
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      red[(r0 * a.C + c + j) * 2 + 0] = s1[j];
+      red[(r0 * a.C + c + j) * 2 + 1] = s2[j];
+    }
+  }
+  __syncthreads();
+  if (tid < a.C) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int g = 0; g < rpp; ++g) {
+      t1 += red[(g * a.C + tid) * 2 + 0];
+      t2 += red[(g * a.C + tid) * 2 + 1];
+    }
+    float* o = a.stats + (((size_t)b * a.ntiles + blockIdx.x) * a.C + tid) * 2;
+    o[0] = t1;
+    o[1] = t2;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// out_conv: y[b][t] = bias + sum_k sum_c w[k][c] * gelu(x[b][t+k-1][c]*scale+shift)
+// Pure read-bound.  Each row's three tap dot-products are formed once (8 channels per lane,
+// shuffle-reduced over the row's lanes), parked in LDS, then combined across neighbours.
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void out_conv_kernel(const OutConvArgs a) {
+  __shared__ float y[3][STAT_TILE + 2];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * STAT_TILE;
+  const int opr = a.C >> 3;  // lanes per row (power of two: 4, 8, 16, ...)
+  const int rpp = 256 / opr;
+  const int oct = tid % opr;
+  const int r0 = tid / opr;
+  const int c = oct * 8;
+  f32x8 sc, sh, w0, w1, w2;
+  {
+    const float2* p = a.ss + (size_t)b * a.C + c;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float2 q = p[j];
+      sc[j] = q.x;
+      sh[j] = q.y;
+      w0[j] = a.w[0 * a.C + c + j];
+      w1[j] = a.w[1 * a.C + c + j];
+      w2[j] = a.w[2 * a.C + c + j];
+    }
+  }
+  const T* xb = reinterpret_cast<const T*>(a.in) + (size_t)b * a.L * a.C + c;
+  for (int r = r0; r < STAT_TILE + 2; r += rpp) {
+    const int t = t0 - 1 + r;
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+    if (t >= 0 && t < a.L) {
+      const f32x8 v = Elem<T>::load8(xb + (size_t)t * a.C);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float g = gelu_f(fmaf(v[j], sc[j], sh[j]));
+        p0 = fmaf(w0[j], g, p0);
+        p1 = fmaf(w1[j], g, p1);
+        p2 = fmaf(w2[j], g, p2);
+      }
+    }
+    for (int m = 1; m < opr; m <<= 1) {
+      p0 += __shfl_xor(p0, m);
+      p1 += __shfl_xor(p1, m);
+      p2 += __shfl_xor(p2, m);
+    }
+    if (oct == 0) {
+      y[0][r] = p0;
+      y[1][r] = p1;
+      y[2][r] = p2;
+    }
+  }
+  __syncthreads();
+  const int t = t0 + tid;
+  if (t < a.L) a.out[(size_t)b * a.L + t] = a.bias + y[0][tid] + y[1][tid + 1] + y[2][tid + 2];
+}
+
+// ------------------------------------------------------------------------------------
+// GroupNorm (+FiLM) coefficients.  One workgroup per clip.  Tile partials are summed in a
+// fixed order in fp64, so the result does not depend on scheduling.
+//   scale = rstd*gamma*(a+1),  shift = (beta - mean*rstd*gamma)*(a+1) + b
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_prepare_kernel(const GnArgs a) {
+  __shared__ double part[256 * 2];
+  __shared__ double chs[1024], chq[1024];
+  __shared__ double gmean[32], grstd[32];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x;
+  int cbase = 0;
+  for (int s = 0; s < a.nsrc; ++s) {
+    const GnSrc g = a.src[s];
+    const float* p = g.partials + (size_t)b * g.ntiles * g.C * 2;
+    for (int c0 = 0; c0 < g.C; c0 += 256) {
+      const int cw = min(256, g.C - c0);         // channels handled this round
+      const int nsl = 256 / cw;                  // tile slices per channel
+      const int c = tid % cw, sl = tid / cw;
+      double s1 = 0.0, s2 = 0.0;
+      if (sl < nsl) {
+        for (int t = sl; t < g.ntiles; t += nsl) {
+          const float2 q = *reinterpret_cast<const float2*>(p + ((size_t)t * g.C + c0 + c) * 2);
+          s1 += (double)q.x;
+          s2 += (double)q.y;
+        }
+        part[tid * 2] = s1;
+        part[tid * 2 + 1] = s2;
+      }
+      __syncthreads();
+      if (tid < cw) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int k = 0; k < nsl; ++k) {
+          t1 += part[(k * cw + tid) * 2];
+          t2 += part[(k * cw + tid) * 2 + 1];
+        }
+        chs[cbase + c0 + tid] = t1;
+        chq[cbase + c0 + tid] = t2;
+      }
+      __syncthreads();
+    }
+    cbase += g.C;
+  }
+  const int gs = a.Ctot / a.groups;
+  if (tid < a.groups) {
+    double t1 = 0.0, t2 = 0.0;
+    for (int j = 0; j < gs; ++j) {
+      t1 += chs[tid * gs + j];
+      t2 += chq[tid * gs + j];
+    }
+    const double mean = t1 * a.inv_count;
+    double var = t2 * a.inv_count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    gmean[tid] = mean;
+    grstd[tid] = 1.0 / sqrt(var + 1e-5);
+  }
+  __syncthreads();
+  for (int c = tid; c < a.Ctot; c += 256) {
+    const int g = c / gs;
+    double scale = grstd[g] * (double)a.gamma[c];
+    double shift = (double)a.beta[c] - gmean[g] * scale;
+    if (a.film) {
+      const float* f = a.film + (size_t)b * a.film_stride + a.film_off;
+      const double fa = (double)f[c] + 1.0;
+      const double fb = (double)f[a.Ctot + c];
+      scale *= fa;
+      shift = shift * fa + fb;
+    }
+    a.ss[(size_t)b * a.Ctot + c] = make_float2((float)scale, (float)shift);
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Timestep embedding: one workgroup per clip, wave-per-output-row mat-vecs.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void time_embed_kernel(const TimeEmbedArgs a) {
+  __shared__ float e0[1024], e1[1024];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x;
+  const int E = a.E, half = E >> 1;
+  const float t = a.ts[b];
+  for (int j = tid; j < half; j += 256) {
+    const float arg = t * a.freqs[j];
+    e0[j] = cosf(arg);
+    e0[half + j] = sinf(arg);
+  }
+  __syncthreads();
+  for (int r = wave; r < E; r += 4) {  // time_embed.proj
+    float acc = 0.f;
+    for (int j = lane; j < E; j += 64) acc = fmaf(a.w1[(size_t)r * E + j], e0[j], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) e1[r] = gelu_f(acc + a.b1[r]);  // time_embed_extra.0 = GELU
+  }
+  __syncthreads();
+  const float* ce = nullptr;
+  if (a.class_embed) {
+    long long lab = a.labels[b];
+    if (lab < 0) lab = 0;
+    if (lab >= a.num_labels) lab = a.num_labels - 1;
+    ce = a.class_embed + (size_t)lab * E;
+  }
+  for (int r = wave; r < E; r += 4) {  // time_embed_extra.1
+    float acc = 0.f;
+    for (int j = lane; j < E; j += 64) acc = fmaf(a.w2[(size_t)r * E + j], e1[j], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      float v = acc + a.b2[r];
+      if (ce) v += ce[r];
+      a.emb[(size_t)b * E + r] = v;
+      a.gemb[(size_t)b * E + r] = gelu_f(v);
+    }
+  }
+}
+
+__global__ void gelu_rows_kernel(const float* in, float* out, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = gelu_f(in[i]);
+}
+
+// film[b][r] = bias[r] + W[r] . gemb[b]; one wave per output row, all clips.
+template <int N>  // N = E / 64
+__global__ __launch_bounds__(256) void film_kernel(const FilmArgs a, int B) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= a.R) return;
+  const int E = a.E;
+  float w[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) w[i] = a.w[(size_t)r * E + i * 64 + lane];
+  const float bias = a.bias[r];
+  for (int b = 0; b < B; ++b) {
+    const float* g = a.gemb + (size_t)b * E;
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc = fmaf(w[i], g[i * 64 + lane], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) a.film[(size_t)b * a.R + r] = acc + bias;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// NCT float32 <-> NTC T, 32x32 tiles through LDS (used only at the library boundary:
+// conditioning input, encoder output, unit-test handles, debug taps).
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void nct_to_ntc_kernel(const float* in, T* out, int C, int L) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, c0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, t = t0 + tx;
+    tile[i][tx] = (c < C && t < L) ? in[((size_t)b * C + c) * L + t] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int t = t0 + i, c = c0 + tx;
+    if (t < L && c < C) out[((size_t)b * L + t) * C + c] = (T)tile[tx][i];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ntc_to_nct_kernel(const T* in, float* out, int C, int L) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, c0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int t = t0 + i, c = c0 + tx;
+    tile[i][tx] = (c < C && t < L) ? (float)in[((size_t)b * L + t) * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, t = t0 + tx;
+    if (t < L && c < C) out[((size_t)b * C + c) * L + t] = tile[tx][i];
+  }
+}
+
+// statistics of an NTC tensor (only for tensors that enter the library from outside)
+template <typename T>
+__global__ __launch_bounds__(256) void ntc_stats_kernel(const T* in, float* stats, int C, int L, int ntiles) {
+  const int b = blockIdx.y, tile = blockIdx.x;
+  const T* p = in + (size_t)b * L * C;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s1 = 0.f, s2 = 0.f;
+    const int t1 = min(L, (tile + 1) * STAT_TILE);
+    for (int t = tile * STAT_TILE; t < t1; ++t) {
+      const float v = (float)p[(size_t)t * C + c];
+      s1 += v;
+      s2 += v * v;
+    }
+    float* o = stats + (((size_t)b * ntiles + tile) * C + c) * 2;
+    o[0] = s1;
+    o[1] = s2;
+  }
+}
+
+}  // namespace
+
+int launch_in_conv(const InConvArgs& a, int B, int precision, hipStream_t st) {
+  if (a.C % 8 || a.C > 256 || (256 % (a.C / 8)) != 0) VQVS_FAIL(-1, "in_conv: unsupported C=%d", a.C);
+  dim3 grid((a.T + STAT_TILE - 1) / STAT_TILE, B);
+  if (precision == 0)
+    hipLaunchKernelGGL(in_conv_kernel<float>, grid, dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(in_conv_kernel<bf16_t>, grid, dim3(256), 0, st, a);
+  VQVS_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_out_conv(const OutConvArgs& a, int B, int precision, hipStream_t st) {
+  const int opr = a.C / 8;
+  if (a.C % 8 || opr > 64 || (opr & (opr - 1))) VQVS_FAIL(-1, "out_conv: unsupported C=%d", a.C);
+  dim3 grid((a.L + STAT_TILE - 1) / STAT_TILE, B);
+  if (precision == 0)
+    hipLaunchKernelGGL(out_conv_kernel<float>, grid, dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(out_conv_kernel<bf16_t>, grid, dim3(256), 0, st, a);
+  VQVS_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_gn_prepare(const GnArgs& a, int B, hipStream_t st) {
+  if (a.Ctot > 1024 || a.groups > 32 || a.Ctot % a.groups) VQVS_FAIL(-1, "gn: unsupported Ctot=%d groups=%d", a.Ctot, a.groups);
+  hipLaunchKernelGGL(gn_prepare_kernel, dim3(B), dim3(256), 0, st, a);
+  VQVS_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_time_embed(const TimeEmbedArgs& a, int B, hipStream_t st) {
+  if (a.E > 1024 || a.E % 64) VQVS_FAIL(-1, "time_embed: unsupported E=%d", a.E);
+  hipLaunchKernelGGL(time_embed_kernel, dim3(B), dim3(256), 0, st, a);
+  VQVS_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_gelu_rows(const float* in, float* out, int n, hipStream_t st) {
+  hipLaunchKernelGGL(gelu_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, st, in, out, n);
+  VQVS_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_film(const FilmArgs& a, int B, hipStream_t st) {
+  const dim3 grid((a.R + 3) / 4), blk(256);
+  switch (a.E) {
+    case 64: hipLaunchKernelGGL(film_kernel<1>, grid, blk, 0, st, a, B); break;
+    case 128: hipLaunchKernelGGL(film_kernel<2>, grid, blk, 0, st, a, B); break;
+    case 256: hipLaunchKernelGGL(film_kernel<4>, grid, blk, 0, st, a, B); break;
+    case 512: hipLaunchKernelGGL(film_kernel<8>, grid, blk, 0, st, a, B); break;
+    case 1024: hipLaunchKernelGGL(film_kernel<16>, grid, blk, 0, st, a, B); break;
+    default: VQVS_FAIL(-1, "film: unsupported E=%d", a.E);
+  }
+  VQVS_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_nct_to_ntc(const float* in, void* out, float* stats, int B, int C, int L, int ntiles, int precision, hipStream_t st) {
+  dim3 grid((L + 31) / 32, (C + 31) / 32, B);
+  if (precision == 0) {
+    hipLaunchKernelGGL(nct_to_ntc_kernel<float>, grid, dim3(256), 0, st, in, (float*)out, C, L);
+    if (stats) hipLaunchKernelGGL(ntc_stats_kernel<float>, dim3(ntiles, B), dim3(256), 0, st, (const float*)out, stats, C, L, ntiles);
+  } else {
+    hipLaunchKernelGGL(nct_to_ntc_kernel<bf16_t>, grid, dim3(256), 0, st, in, (bf16_t*)out, C, L);
+    if (stats) hipLaunchKernelGGL(ntc_stats_kernel<bf16_t>, dim3(ntiles, B), dim3(256), 0, st, (const bf16_t*)out, stats, C, L, ntiles);
+  }
+  VQVS_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_ntc_to_nct(const void* in, float* out, int B, int C, int L, int in_precision, hipStream_t st) {
+  dim3 grid((L + 31) / 32, (C + 31) / 32, B);
+  if (in_precision == 0)
+    hipLaunchKernelGGL(ntc_to_nct_kernel<float>, grid, dim3(256), 0, st, (const float*)in, out, C, L);
+  else
+    hipLaunchKernelGGL(ntc_to_nct_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)in, out, C, L);
+  VQVS_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace vqvs

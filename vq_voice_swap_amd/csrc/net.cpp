@@ -1,0 +1,757 @@
+// Topology of the reference's UNets (reference vq_voice_swap/models/unet.py:17-116, 188-227),
+// restated as a static schedule of fused kernels.  Per ResBlock (unet.py:248-316):
+//
+//   gn_prepare(x stats, pre_cond.0.0)                 -> scale/shift of GroupNorm 1
+//   conv  [GN1+GELU -> resize -> Conv3]               -> h1   (+ statistics of h1)
+//   gn_prepare(h1 stats, pre_cond.3, FiLM a|b)        -> scale/shift of GroupNorm 2 (+FiLM)
+//   conv  [GN2*FiLM+GELU -> dilated Conv3] + skip     -> out  (+ statistics of out)
+//
+// i.e. two streaming passes over the activations per block (SURVEY.md 8d "Model A").
+#include "net.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+namespace vqvs {
+
+namespace {
+
+const int CH_MULT[9] = {1, 1, 2, 2, 2, 4, 4, 8, 8};  // unet.py:20
+const int MID_DIL[4] = {4, 8, 16, 32};               // unet.py:21
+constexpr int DEPTH_MULT = 2;                        // unet.py:22
+constexpr int NLEVEL = 9;
+
+struct BlockSpec {
+  std::string prefix;
+  int cin, cout, resize, dil;
+  bool cat;
+};
+
+void predictor_blocks(int base, std::vector<BlockSpec>& down, std::vector<BlockSpec>& mid, std::vector<BlockSpec>& up) {
+  std::vector<int> stack{base};
+  int cur = base;
+  for (int depth = 0; depth < NLEVEL; ++depth) {
+    const int mult = CH_MULT[depth];
+    for (int i = 0; i < DEPTH_MULT; ++i) {
+      down.push_back({"down_blocks." + std::to_string(down.size()), cur, mult * base, RESIZE_NONE, 2, false});
+      cur = mult * base;
+      stack.push_back(cur);
+    }
+    if (depth != NLEVEL - 1) {
+      down.push_back({"down_blocks." + std::to_string(down.size()), cur, cur, RESIZE_AVG2, 2, false});
+      stack.push_back(cur);
+    }
+  }
+  for (int i = 0; i < 4; ++i) mid.push_back({"middle_blocks." + std::to_string(i), cur, cur, RESIZE_NONE, MID_DIL[i], false});
+  for (int depth = NLEVEL - 1; depth >= 0; --depth) {
+    const int mult = CH_MULT[depth];
+    for (int i = 0; i < DEPTH_MULT + 1; ++i) {
+      const int sk = stack.back();
+      stack.pop_back();
+      up.push_back({"up_blocks." + std::to_string(up.size()), cur + sk, mult * base, RESIZE_NONE, 2, true});
+      cur = mult * base;
+    }
+    if (depth) up.push_back({"up_blocks." + std::to_string(up.size()), cur, cur, RESIZE_UP2, 2, false});
+  }
+}
+
+void encoder_blocks(int base, std::vector<BlockSpec>& blocks) {
+  int cur = base;
+  for (int depth = 0; depth < NLEVEL; ++depth) {
+    const int mult = CH_MULT[depth];
+    for (int i = 0; i < DEPTH_MULT; ++i) {
+      blocks.push_back({"blocks." + std::to_string(blocks.size()), cur, mult * base, RESIZE_NONE, 2, false});
+      cur = mult * base;
+    }
+    if (depth != NLEVEL - 1) blocks.push_back({"blocks." + std::to_string(blocks.size()), cur, cur, RESIZE_AVG2, 2, false});
+  }
+}
+
+void block_params(std::vector<ParamDef>& out, const std::string& p, const BlockSpec& s, int emb, bool dropout) {
+  const std::string pre = p.empty() ? "" : p + ".";
+  out.push_back({pre + "pre_cond.0.0.weight", {s.cin}});
+  out.push_back({pre + "pre_cond.0.0.bias", {s.cin}});
+  out.push_back({pre + "pre_cond.2.weight", {s.cout, s.cin, 3}});
+  out.push_back({pre + "pre_cond.2.bias", {s.cout}});
+  out.push_back({pre + "pre_cond.3.weight", {s.cout}});
+  out.push_back({pre + "pre_cond.3.bias", {s.cout}});
+  if (emb) {
+    out.push_back({pre + "cond_layers.1.weight", {2 * s.cout, emb}});
+    out.push_back({pre + "cond_layers.1.bias", {2 * s.cout}});
+  }
+  const std::string c2 = pre + (dropout ? "post_cond.2" : "post_cond.1");  // unet.py:295-305
+  out.push_back({c2 + ".weight", {s.cout, s.cout, 3}});
+  out.push_back({c2 + ".bias", {s.cout}});
+  if (s.cin != s.cout) {
+    out.push_back({pre + "skip.1.weight", {s.cout, s.cin, 1}});
+    out.push_back({pre + "skip.1.bias", {s.cout}});
+  }
+}
+
+bool cfg_dropout(const vqvs_cfg& c) { return c.reserved[0] != 0; }
+
+uint16_t f2bf(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+float bf2f(uint16_t h) {
+  const uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+struct Blob {
+  std::vector<char> data;
+  size_t add(const void* p, size_t bytes) {
+    size_t off = (data.size() + 255) & ~(size_t)255;
+    data.resize(off + bytes);
+    if (p) memcpy(data.data() + off, p, bytes);
+    return off;
+  }
+};
+
+// conv weights in MFMA B-operand order: [segment][chunk of 32 ci][tap][Cout][32 ci]
+struct PackedConv {
+  std::vector<uint16_t> hi, lo;
+  long long append(const float* W, int Cout, int Cin_total, int ktaps, int cb, int C) {
+    const long long off = (long long)hi.size();
+    for (int ch = 0; ch < C / 32; ++ch)
+      for (int k = 0; k < ktaps; ++k)
+        for (int co = 0; co < Cout; ++co)
+          for (int j = 0; j < 32; ++j) {
+            const float w = W[((size_t)co * Cin_total + cb + ch * 32 + j) * ktaps + k];
+            const uint16_t h = f2bf(w);
+            hi.push_back(h);
+            lo.push_back(f2bf(w - bf2f(h)));
+          }
+    return off;
+  }
+};
+
+double lscale(int lshift) { return lshift >= 0 ? 1.0 / (double)(1 << lshift) : (double)(1 << -lshift); }
+int shiftL(int L, int lshift) { return lshift >= 0 ? (L >> lshift) : (L << -lshift); }
+int ntiles_of(int L) { return (L + STAT_TILE - 1) / STAT_TILE; }
+
+class Builder {
+ public:
+  Builder(vqvs_model* m, const float* const* hp) : m_(m), hp_(hp) {
+    for (size_t i = 0; i < m->params.size(); ++i) pidx_[m->params[i].name] = (int)i;
+    es_ = m->cfg.precision == VQVS_PREC_F32 ? 4 : 2;
+    maxB_ = m->cfg.max_batch;
+    maxL_ = m->cfg.max_T;
+  }
+
+  const float* P(const std::string& name) const {
+    auto it = pidx_.find(name);
+    if (it == pidx_.end()) return nullptr;
+    return hp_[it->second];
+  }
+  size_t blob_f32(const std::string& name) {
+    auto it = pidx_.find(name);
+    return blob.add(hp_[it->second], m_->params[it->second].numel() * 4);
+  }
+
+  // ---- arena planning -------------------------------------------------------------
+  TensorH new_tensor(int C, int lshift, bool f32, bool stats) {
+    TensorH t;
+    t.id = next_id_++;
+    t.C = C;
+    t.lshift = lshift;
+    t.f32 = f32;
+    const size_t bytes = ((size_t)maxB_ * shiftL(maxL_, lshift) * C * (f32 ? 4 : es_) + 255) & ~(size_t)255;
+    t.off = arena_alloc(bytes);
+    sizes_[t.id] = bytes;
+    offs_[t.id] = t.off;
+    refs_[t.id] = 1;
+    if (stats) {
+      t.has_stats = true;
+      t.stats_off = stats_floats;
+      stats_floats += (size_t)maxB_ * ntiles_of(shiftL(maxL_, lshift)) * C * 2;
+    }
+    return t;
+  }
+  void retain(const TensorH& t) { refs_[t.id]++; }
+  void release(const TensorH& t) {
+    if (--refs_[t.id] == 0 && !m_->cfg.debug_taps) arena_free(offs_[t.id], sizes_[t.id]);
+  }
+  size_t alloc_ss(int C) {
+    const size_t off = ss_floats;
+    ss_floats += (size_t)maxB_ * C * 2;
+    return off;
+  }
+  size_t alloc_misc(size_t floats) {
+    const size_t off = misc_floats;
+    misc_floats += (floats + 63) & ~(size_t)63;
+    return off;
+  }
+
+  // ---- pointer resolution at run time ------------------------------------------------
+  // (regions are laid out after planning: [activations | stats | ss | misc])
+  char* act(size_t off) const { return m_->d_arena + off; }
+  float* statp(size_t foff) const { return reinterpret_cast<float*>(m_->d_arena + m_->stats_off) + foff; }
+  float* ssp(size_t foff) const { return reinterpret_cast<float*>(m_->d_arena + m_->ss_off) + foff; }
+  float* miscp(size_t foff) const { return reinterpret_cast<float*>(m_->d_arena + m_->misc_off) + foff; }
+  char* wp(size_t off) const { return m_->d_weights + off; }
+
+  // ---- ops ---------------------------------------------------------------------------
+  void add_gn(const std::vector<TensorH>& srcs, const std::string& gn_name, bool film, int film_off, int film_stride,
+              size_t film_misc_off, size_t ss_off) {
+    int Ctot = 0;
+    for (auto& s : srcs) Ctot += s.C;
+    const size_t g_off = blob_f32(gn_name + ".weight");
+    const size_t b_off = blob_f32(gn_name + ".bias");
+    const int groups = gn_groups(Ctot);
+    const int lshift = srcs[0].lshift;
+    Builder* self = this;
+    std::vector<TensorH> S = srcs;
+    m_->ops.push_back([=](const RunCtx& c) -> int {
+      GnArgs a{};
+      const int L = shiftL(c.Lbase, lshift);
+      a.nsrc = (int)S.size();
+      for (int i = 0; i < a.nsrc; ++i) a.src[i] = GnSrc{self->statp(S[i].stats_off), ntiles_of(L), S[i].C};
+      a.Ctot = Ctot;
+      a.groups = groups;
+      a.inv_count = 1.0 / ((double)(Ctot / groups) * (double)L);
+      a.gamma = reinterpret_cast<const float*>(self->wp(g_off));
+      a.beta = reinterpret_cast<const float*>(self->wp(b_off));
+      a.film = film ? self->miscp(film_misc_off) : nullptr;
+      a.film_stride = film_stride;
+      a.film_off = film_off;
+      a.ss = reinterpret_cast<float2*>(self->ssp(ss_off));
+      return launch_gn_prepare(a, c.B, c.st);
+    });
+  }
+
+  struct SegSpec {
+    TensorH t;
+    int c0, C, ntaps, dil, resize;
+    bool xform;
+    size_t ss_off;
+    int ss_stride, ss_c0;
+    long long w_off;
+  };
+
+  void add_conv(const std::vector<SegSpec>& segs, const PackedConv& pk, const std::vector<float>& bias, int Cout, const TensorH& out,
+                const TensorH* skip, int skip_resize) {
+    const size_t hi_off = blob.add(pk.hi.data(), pk.hi.size() * 2);
+    const size_t lo_off = m_->cfg.precision == VQVS_PREC_F32 ? blob.add(pk.lo.data(), pk.lo.size() * 2) : 0;
+    const size_t bias_off = blob.add(bias.data(), bias.size() * 4);
+    const bool x3 = m_->cfg.precision == VQVS_PREC_F32;
+    const int prec = m_->cfg.precision;
+    Builder* self = this;
+    std::vector<SegSpec> S = segs;
+    const TensorH O = out;
+    const bool has_skip = skip != nullptr;
+    const TensorH K = skip ? *skip : TensorH{};
+    // cost
+    double ktot = 0;
+    for (auto& s : segs) {
+      m_->cost.elems_T += s.C * lscale(s.t.lshift);
+      ktot += (double)s.C * s.ntaps;
+    }
+    if (skip) m_->cost.elems_T += K.C * lscale(K.lshift);
+    if (out.f32) m_->cost.bytes_f32 += 4.0 * Cout * lscale(out.lshift);
+    else m_->cost.elems_T += Cout * lscale(out.lshift);
+    m_->cost.flops += 2.0 * Cout * ktot * lscale(out.lshift);
+    m_->ops.push_back([=](const RunCtx& c) -> int {
+      ConvArgs a{};
+      a.nseg = (int)S.size();
+      for (int i = 0; i < a.nseg; ++i) {
+        SegDesc& g = a.seg[i];
+        g.src = self->act(S[i].t.off);
+        g.ss = S[i].xform ? reinterpret_cast<const float2*>(self->ssp(S[i].ss_off)) : nullptr;
+        g.w_off = S[i].w_off;
+        g.Csrc = S[i].t.C;
+        g.c0 = S[i].c0;
+        g.C = S[i].C;
+        g.Lsrc = shiftL(c.Lbase, S[i].t.lshift);
+        g.ntaps = S[i].ntaps;
+        g.dil = S[i].dil;
+        g.resize = S[i].resize;
+        g.ss_stride = S[i].ss_stride;
+        g.ss_c0 = S[i].ss_c0;
+      }
+      a.w_hi = reinterpret_cast<const bf16_t*>(self->wp(hi_off));
+      a.w_lo = x3 ? reinterpret_cast<const bf16_t*>(self->wp(lo_off)) : nullptr;
+      a.bias = reinterpret_cast<const float*>(self->wp(bias_off));
+      a.Cout = Cout;
+      a.Lout = shiftL(c.Lbase, O.lshift);
+      if (has_skip) {
+        a.skip = self->act(K.off);
+        a.skip_C = K.C;
+        a.skip_L = shiftL(c.Lbase, K.lshift);
+        a.skip_resize = skip_resize;
+      }
+      a.out = self->act(O.off);
+      a.out_f32 = O.f32 ? 1 : 0;
+      a.stats = O.has_stats ? self->statp(O.stats_off) : nullptr;
+      a.ntiles = ntiles_of(a.Lout);
+      return launch_conv(a, c.B, prec, c.st);
+    });
+  }
+
+  // One reference ResBlock (unet.py:248-316).  `ins` = 1 tensor, or 2 for torch.cat([h, skip], 1).
+  // film_misc_off/film_off/film_stride locate this block's (a|b) rows; emb = false for the encoder.
+  TensorH resblock(const std::string& p, const BlockSpec& s, const std::vector<TensorH>& ins, bool emb, int film_off, int film_stride,
+                   size_t film_misc_off) {
+    const std::string pre = p.empty() ? "" : p + ".";
+    const int cin = s.cin, cout = s.cout;
+    const int in_shift = ins[0].lshift;
+    const int out_shift = in_shift + (s.resize == RESIZE_AVG2 ? 1 : (s.resize == RESIZE_UP2 ? -1 : 0));
+    // GroupNorm 1 coefficients over the (virtually concatenated) input
+    const size_t ss1 = alloc_ss(cin);
+    add_gn(ins, pre + "pre_cond.0.0", false, 0, 0, 0, ss1);
+    // conv 1
+    TensorH h1 = new_tensor(cout, out_shift, false, true);
+    {
+      PackedConv pk;
+      std::vector<SegSpec> segs;
+      const float* W = P(pre + "pre_cond.2.weight");
+      int cb = 0;
+      for (auto& t : ins) {
+        SegSpec g{t, 0, t.C, 3, 1, s.resize, true, ss1, cin, cb, 0};
+        g.w_off = pk.append(W, cout, cin, 3, cb, t.C);
+        segs.push_back(g);
+        cb += t.C;
+      }
+      const float* b = P(pre + "pre_cond.2.bias");
+      add_conv(segs, pk, std::vector<float>(b, b + cout), cout, h1, nullptr, 0);
+    }
+    // GroupNorm 2 (+FiLM) coefficients
+    const size_t ss2 = alloc_ss(cout);
+    add_gn({h1}, pre + "pre_cond.3", emb, film_off, film_stride, film_misc_off, ss2);
+    // conv 2 + skip
+    TensorH out = new_tensor(cout, out_shift, false, true);
+    {
+      PackedConv pk;
+      std::vector<SegSpec> segs;
+      const std::string c2 = pre + (cfg_dropout(m_->cfg) ? "post_cond.2" : "post_cond.1");
+      const float* W = P(c2 + ".weight");
+      const float* b = P(c2 + ".bias");
+      std::vector<float> bias(b, b + cout);
+      SegSpec g{h1, 0, cout, 3, s.dil, RESIZE_NONE, true, ss2, cout, 0, 0};
+      g.w_off = pk.append(W, cout, cout, 3, 0, cout);
+      segs.push_back(g);
+      if (cin != cout) {  // 1x1 skip conv folded into the same GEMM as raw 1-tap segments
+        const float* Ws = P(pre + "skip.1.weight");
+        const float* bs = P(pre + "skip.1.bias");
+        for (int i = 0; i < cout; ++i) bias[i] += bs[i];
+        int cb = 0;
+        for (auto& t : ins) {
+          SegSpec r{t, 0, t.C, 1, 1, RESIZE_NONE, false, 0, 0, 0, 0};
+          r.w_off = pk.append(Ws, cout, cin, 1, cb, t.C);
+          segs.push_back(r);
+          cb += t.C;
+        }
+        add_conv(segs, pk, bias, cout, out, nullptr, 0);
+      } else {  // identity skip (never together with a concatenated input in this topology)
+        add_conv(segs, pk, bias, cout, out, &ins[0], s.resize);
+      }
+    }
+    release(h1);
+    return out;
+  }
+
+  void tap(const std::string& name, const TensorH& t) { m_->taps.push_back({name, t}); }
+
+  // region sizes after planning
+  size_t act_high = 0, stats_floats = 0, ss_floats = 0, misc_floats = 0;
+  Blob blob;
+  int es() const { return es_; }
+
+ private:
+  size_t arena_alloc(size_t bytes) {
+    for (size_t i = 0; i < free_.size(); ++i) {
+      if (free_[i].second >= bytes) {
+        const size_t off = free_[i].first;
+        if (free_[i].second == bytes) free_.erase(free_.begin() + i);
+        else { free_[i].first += bytes; free_[i].second -= bytes; }
+        return off;
+      }
+    }
+    const size_t off = act_high;
+    act_high += bytes;
+    return off;
+  }
+  void arena_free(size_t off, size_t bytes) {
+    free_.push_back({off, bytes});
+    // coalesce
+    std::sort(free_.begin(), free_.end());
+    std::vector<std::pair<size_t, size_t>> merged;
+    for (auto& f : free_) {
+      if (!merged.empty() && merged.back().first + merged.back().second == f.first) merged.back().second += f.second;
+      else merged.push_back(f);
+    }
+    // a free block that ends at the high-water mark is given back
+    if (!merged.empty() && merged.back().first + merged.back().second == act_high) {
+      // keep the high-water mark (arena size is the maximum ever needed)
+    }
+    free_ = merged;
+  }
+
+  vqvs_model* m_;
+  const float* const* hp_;
+  std::map<std::string, int> pidx_;
+  int es_, maxB_, maxL_;
+  int next_id_ = 0;
+  std::map<int, size_t> sizes_, offs_;
+  std::map<int, int> refs_;
+  std::vector<std::pair<size_t, size_t>> free_;
+};
+
+}  // namespace
+
+int gn_groups(int ch) {  // unet.py:345-349
+  int g = 32;
+  while (ch % g) g /= 2;
+  return g;
+}
+
+int enumerate_params(const vqvs_cfg& c, std::vector<ParamDef>& out) {
+  out.clear();
+  const int base = c.base_channels;
+  const bool drop = cfg_dropout(c);
+  if (c.kind == VQVS_KIND_PREDICTOR) {
+    const int E = 4 * base;
+    out.push_back({"time_embed.proj.weight", {E, E}});
+    out.push_back({"time_embed.proj.bias", {E}});
+    out.push_back({"time_embed_extra.1.weight", {E, E}});
+    out.push_back({"time_embed_extra.1.bias", {E}});
+    if (c.num_labels > 0) out.push_back({"class_embed.weight", {c.num_labels, E}});
+    if (c.cond_channels > 0) {
+      out.push_back({"cond_proj.weight", {base, c.cond_channels, 3}});
+      out.push_back({"cond_proj.bias", {base}});
+    }
+    out.push_back({"in_conv.weight", {base, c.in_channels, 3}});
+    out.push_back({"in_conv.bias", {base}});
+    std::vector<BlockSpec> d, mdl, u;
+    predictor_blocks(base, d, mdl, u);
+    for (auto& s : d) block_params(out, s.prefix, s, E, drop);
+    for (auto& s : mdl) block_params(out, s.prefix, s, E, drop);
+    for (auto& s : u) block_params(out, s.prefix, s, E, drop);
+    out.push_back({"out.0.0.weight", {base}});
+    out.push_back({"out.0.0.bias", {base}});
+    out.push_back({"out.1.weight", {c.out_channels, base, 3}});
+    out.push_back({"out.1.bias", {c.out_channels}});
+  } else if (c.kind == VQVS_KIND_ENCODER) {
+    out.push_back({"in_conv.weight", {base, c.in_channels, 3}});
+    out.push_back({"in_conv.bias", {base}});
+    std::vector<BlockSpec> blocks;
+    encoder_blocks(base, blocks);
+    for (auto& s : blocks) block_params(out, s.prefix, s, 0, false);
+    const int cur = 8 * base;
+    out.push_back({"out.0.0.weight", {cur}});
+    out.push_back({"out.0.0.bias", {cur}});
+    out.push_back({"out.1.weight", {c.out_channels, cur, 3}});
+    out.push_back({"out.1.bias", {c.out_channels}});
+  } else if (c.kind == VQVS_KIND_RESBLOCK) {
+    BlockSpec s{"", c.rb_cin, c.rb_cout, c.rb_resize, c.rb_dilation, false};
+    block_params(out, "", s, c.rb_emb_channels, drop);
+  } else {
+    VQVS_FAIL(VQVS_ERR_ARG, "unknown model kind %d", c.kind);
+  }
+  return 0;
+}
+
+static int check_cfg(const vqvs_cfg& c) {
+  if (c.precision != VQVS_PREC_F32 && c.precision != VQVS_PREC_BF16) VQVS_FAIL(VQVS_ERR_ARG, "bad precision %d", c.precision);
+  if (c.max_batch < 1 || c.max_T < 1) VQVS_FAIL(VQVS_ERR_ARG, "max_batch/max_T must be positive");
+  if (c.kind == VQVS_KIND_RESBLOCK) {
+    if (c.rb_cin % 32 || c.rb_cout % 32 || c.rb_cin < 32 || c.rb_cout < 32) VQVS_FAIL(VQVS_ERR_ARG, "resblock channels must be multiples of 32");
+    if (c.rb_dilation < 1 || c.rb_dilation > 32) VQVS_FAIL(VQVS_ERR_ARG, "resblock dilation must be in 1..32");
+    if (c.rb_resize != RESIZE_NONE && c.rb_cin != c.rb_cout) VQVS_FAIL(VQVS_ERR_ARG, "resizing resblock cannot change channels");
+    if (c.rb_emb_channels % 64) VQVS_FAIL(VQVS_ERR_ARG, "resblock emb channels must be a multiple of 64");
+    return 0;
+  }
+  if (c.base_channels < 32 || c.base_channels % 32 || c.base_channels > 128) VQVS_FAIL(VQVS_ERR_ARG, "base_channels must be 32, 64, 96 or 128 (got %d)", c.base_channels);
+  if (c.base_channels & (c.base_channels - 1)) VQVS_FAIL(VQVS_ERR_ARG, "base_channels must be a power of two (got %d)", c.base_channels);
+  if (c.in_channels != 1) VQVS_FAIL(VQVS_ERR_ARG, "in_channels must be 1 (got %d)", c.in_channels);
+  if (c.max_T % 256) VQVS_FAIL(VQVS_ERR_ARG, "max_T must be a multiple of 256 (got %d)", c.max_T);
+  if (c.kind == VQVS_KIND_PREDICTOR) {
+    if (c.out_channels != 1 && (c.out_channels % 32)) VQVS_FAIL(VQVS_ERR_ARG, "out_channels must be 1 or a multiple of 32");
+    if (c.cond_channels % 32) VQVS_FAIL(VQVS_ERR_ARG, "cond_channels must be a multiple of 32");
+  } else {
+    if (c.out_channels % 32 || c.out_channels < 32) VQVS_FAIL(VQVS_ERR_ARG, "encoder out_channels must be a multiple of 32");
+  }
+  return 0;
+}
+
+int build_model(vqvs_model* m, const float* const* hp) {
+  const vqvs_cfg& c = m->cfg;
+  if (int e = check_cfg(c)) return e;
+  if (int e = enumerate_params(c, m->params)) return e;
+  const int prec = c.precision;
+  const int base = c.base_channels;
+  // NOTE: the builder object must outlive the ops (lambdas capture it for pointer resolution).
+  auto keep = std::make_shared<Builder>(m, hp);
+  m->keepalive = keep;
+  Builder* bp = keep.get();
+  Builder& b = *bp;
+
+  if (c.kind == VQVS_KIND_RESBLOCK) {
+    BlockSpec s{"", c.rb_cin, c.rb_cout, c.rb_resize, c.rb_dilation, false};
+    const int E = c.rb_emb_channels;
+    TensorH x = b.new_tensor(c.rb_cin, 0, false, true);
+    const int Cin = c.rb_cin;
+    m->ops.push_back([=](const RunCtx& r) -> int {
+      return launch_nct_to_ntc(r.x, bp->act(x.off), bp->statp(x.stats_off), r.B, Cin, r.Lbase, ntiles_of(r.Lbase), prec, r.st);
+    });
+    size_t film_misc = 0;
+    if (E) {
+      const size_t gemb = b.alloc_misc((size_t)c.max_batch * E);
+      film_misc = b.alloc_misc((size_t)c.max_batch * 2 * c.rb_cout);
+      const size_t w_off = b.blob_f32("cond_layers.1.weight");
+      const size_t bias_off = b.blob_f32("cond_layers.1.bias");
+      const int R = 2 * c.rb_cout;
+      m->ops.push_back([=](const RunCtx& r) -> int {
+        if (!r.emb) VQVS_FAIL(VQVS_ERR_ARG, "resblock handle was built with an embedding; d_emb is NULL");
+        if (int e = launch_gelu_rows(r.emb, bp->miscp(gemb), r.B * E, r.st)) return e;
+        FilmArgs f{bp->miscp(gemb), reinterpret_cast<const float*>(bp->wp(w_off)), reinterpret_cast<const float*>(bp->wp(bias_off)),
+                   bp->miscp(film_misc), E, R};
+        return launch_film(f, r.B, r.st);
+      });
+    }
+    TensorH y = b.resblock("", s, {x}, E != 0, 0, 2 * c.rb_cout, film_misc);
+    const int Cout = c.rb_cout;
+    m->ops.push_back([=](const RunCtx& r) -> int {
+      return launch_ntc_to_nct(bp->act(y.off), r.out, r.B, Cout, shiftL(r.Lbase, y.lshift), prec, r.st);
+    });
+    b.tap("out", y);
+  } else if (c.kind == VQVS_KIND_PREDICTOR) {
+    const int E = 4 * base;
+    std::vector<BlockSpec> d, mdl, u;
+    predictor_blocks(base, d, mdl, u);
+    // ---- embedding + all blocks' FiLM rows
+    std::vector<float> freqs(E / 2);
+    for (int i = 0; i < E / 2; ++i)  // wavegrad.py:361-369 (float32 tensor math)
+      freqs[i] = (float)(std::exp((double)(float)(-std::log(100.0 / 0.1)) * (double)i / (double)(E / 2 - 1))) * 100.0f;
+    const size_t freq_off = b.blob.add(freqs.data(), freqs.size() * 4);
+    const size_t w1 = b.blob_f32("time_embed.proj.weight"), b1 = b.blob_f32("time_embed.proj.bias");
+    const size_t w2 = b.blob_f32("time_embed_extra.1.weight"), b2 = b.blob_f32("time_embed_extra.1.bias");
+    const size_t ce = c.num_labels > 0 ? b.blob_f32("class_embed.weight") : 0;
+    const size_t emb_off = b.alloc_misc((size_t)c.max_batch * E);
+    const size_t gemb_off = b.alloc_misc((size_t)c.max_batch * E);
+    const int NL = c.num_labels;
+    m->ops.push_back([=](const RunCtx& r) -> int {
+      TimeEmbedArgs a{};
+      a.ts = r.ts;
+      a.freqs = reinterpret_cast<const float*>(bp->wp(freq_off));
+      a.w1 = reinterpret_cast<const float*>(bp->wp(w1));
+      a.b1 = reinterpret_cast<const float*>(bp->wp(b1));
+      a.w2 = reinterpret_cast<const float*>(bp->wp(w2));
+      a.b2 = reinterpret_cast<const float*>(bp->wp(b2));
+      a.class_embed = NL > 0 ? reinterpret_cast<const float*>(bp->wp(ce)) : nullptr;
+      a.labels = r.labels;
+      a.num_labels = NL;
+      a.emb = bp->miscp(emb_off);
+      a.gemb = bp->miscp(gemb_off);
+      a.E = E;
+      return launch_time_embed(a, r.B, r.st);
+    });
+    std::vector<const BlockSpec*> all;
+    for (auto& s : d) all.push_back(&s);
+    for (auto& s : mdl) all.push_back(&s);
+    for (auto& s : u) all.push_back(&s);
+    std::vector<int> film_row(all.size());
+    int R = 0;
+    std::vector<float> Wall, ball;
+    for (size_t i = 0; i < all.size(); ++i) {
+      film_row[i] = R;
+      const float* W = b.P(all[i]->prefix + ".cond_layers.1.weight");
+      const float* bb = b.P(all[i]->prefix + ".cond_layers.1.bias");
+      const int rows = 2 * all[i]->cout;
+      Wall.insert(Wall.end(), W, W + (size_t)rows * E);
+      ball.insert(ball.end(), bb, bb + rows);
+      R += rows;
+    }
+    const size_t wall_off = b.blob.add(Wall.data(), Wall.size() * 4);
+    const size_t ball_off = b.blob.add(ball.data(), ball.size() * 4);
+    const size_t film_off = b.alloc_misc((size_t)c.max_batch * R);
+    m->ops.push_back([=](const RunCtx& r) -> int {
+      FilmArgs f{bp->miscp(gemb_off), reinterpret_cast<const float*>(bp->wp(wall_off)), reinterpret_cast<const float*>(bp->wp(ball_off)),
+                 bp->miscp(film_off), E, R};
+      return launch_film(f, r.B, r.st);
+    });
+    // ---- conditioning projection (unet.py:46-47, 138-139)
+    TensorH condp{};
+    const bool has_cond = c.cond_channels > 0;
+    if (has_cond) {
+      TensorH ct = b.new_tensor(c.cond_channels, 8, false, false);
+      const int CC = c.cond_channels;
+      m->ops.push_back([=](const RunCtx& r) -> int {
+        return launch_nct_to_ntc(r.cond, bp->act(ct.off), nullptr, r.B, CC, r.Lbase >> 8, 0, prec, r.st);
+      });
+      condp = b.new_tensor(base, 8, false, false);
+      PackedConv pk;
+      Builder::SegSpec g{ct, 0, CC, 3, 1, RESIZE_NONE, false, 0, 0, 0, 0};
+      g.w_off = pk.append(b.P("cond_proj.weight"), base, CC, 3, 0, CC);
+      const float* bb = b.P("cond_proj.bias");
+      b.add_conv({g}, pk, std::vector<float>(bb, bb + base), base, condp, nullptr, 0);
+      b.release(ct);
+    }
+    // ---- in_conv
+    TensorH h = b.new_tensor(base, 0, false, true);
+    {
+      const size_t w = b.blob_f32("in_conv.weight"), bi = b.blob_f32("in_conv.bias");
+      const TensorH cp = condp;
+      m->cost.bytes_f32 += 4.0;
+      m->cost.elems_T += base + (has_cond ? base / 256.0 : 0.0);
+      m->ops.push_back([=](const RunCtx& r) -> int {
+        InConvArgs a{};
+        a.x = r.x;
+        a.w = reinterpret_cast<const float*>(bp->wp(w));
+        a.bias = reinterpret_cast<const float*>(bp->wp(bi));
+        a.condp = has_cond ? bp->act(cp.off) : nullptr;
+        a.cond_rate = 256;
+        a.out = bp->act(h.off);
+        a.stats = bp->statp(h.stats_off);
+        a.C = base;
+        a.T = r.Lbase;
+        a.ntiles = ntiles_of(r.Lbase);
+        return launch_in_conv(a, r.B, prec, r.st);
+      });
+    }
+    if (has_cond) b.release(condp);
+    b.tap("in_conv", h);
+    // ---- down / middle / up with the skip stack (unet.py:141-160)
+    std::vector<TensorH> skips{h};
+    b.retain(h);  // one reference held by `h`, one by the stack
+    size_t bi = 0;
+    for (auto& s : d) {
+      TensorH o = b.resblock(s.prefix, s, {h}, true, film_row[bi++], R, film_off);
+      b.release(h);
+      h = o;
+      skips.push_back(h);
+      b.retain(h);
+      b.tap(s.prefix, h);
+    }
+    for (auto& s : mdl) {
+      TensorH o = b.resblock(s.prefix, s, {h}, true, film_row[bi++], R, film_off);
+      b.release(h);
+      h = o;
+      b.tap(s.prefix, h);
+    }
+    for (auto& s : u) {
+      TensorH o;
+      if (s.cat) {
+        TensorH sk = skips.back();
+        skips.pop_back();
+        o = b.resblock(s.prefix, s, {h, sk}, true, film_row[bi++], R, film_off);
+        b.release(sk);
+      } else {
+        o = b.resblock(s.prefix, s, {h}, true, film_row[bi++], R, film_off);
+      }
+      b.release(h);
+      h = o;
+      b.tap(s.prefix, h);
+    }
+    // ---- output head (unet.py:113-116, 162)
+    const size_t ss = b.alloc_ss(base);
+    b.add_gn({h}, "out.0.0", false, 0, 0, 0, ss);
+    if (c.out_channels == 1) {
+      const float* W = b.P("out.1.weight");  // [1][base][3] -> [3][base]
+      std::vector<float> wt(3 * base);
+      for (int k = 0; k < 3; ++k)
+        for (int ci = 0; ci < base; ++ci) wt[k * base + ci] = W[ci * 3 + k];
+      const size_t w = b.blob.add(wt.data(), wt.size() * 4);
+      const float bias = b.P("out.1.bias")[0];
+      m->cost.elems_T += base;
+      m->cost.bytes_f32 += 4.0;
+      m->ops.push_back([=](const RunCtx& r) -> int {
+        OutConvArgs a{};
+        a.in = bp->act(h.off);
+        a.ss = reinterpret_cast<const float2*>(bp->ssp(ss));
+        a.w = reinterpret_cast<const float*>(bp->wp(w));
+        a.bias = bias;
+        a.out = r.out;
+        a.C = base;
+        a.L = r.Lbase;
+        return launch_out_conv(a, r.B, prec, r.st);
+      });
+    } else {
+      TensorH o = b.new_tensor(c.out_channels, 0, true, false);
+      PackedConv pk;
+      Builder::SegSpec g{h, 0, base, 3, 1, RESIZE_NONE, true, ss, base, 0, 0};
+      g.w_off = pk.append(b.P("out.1.weight"), c.out_channels, base, 3, 0, base);
+      const float* bb = b.P("out.1.bias");
+      b.add_conv({g}, pk, std::vector<float>(bb, bb + c.out_channels), c.out_channels, o, nullptr, 0);
+      const int OC = c.out_channels;
+      m->ops.push_back([=](const RunCtx& r) -> int { return launch_ntc_to_nct(bp->act(o.off), r.out, r.B, OC, r.Lbase, 0, r.st); });
+    }
+  } else {  // encoder (unet.py:229-241)
+    std::vector<BlockSpec> blocks;
+    encoder_blocks(base, blocks);
+    TensorH h = b.new_tensor(base, 0, false, true);
+    {
+      const size_t w = b.blob_f32("in_conv.weight"), bi = b.blob_f32("in_conv.bias");
+      m->cost.bytes_f32 += 4.0;
+      m->cost.elems_T += base;
+      m->ops.push_back([=](const RunCtx& r) -> int {
+        InConvArgs a{};
+        a.x = r.x;
+        a.w = reinterpret_cast<const float*>(bp->wp(w));
+        a.bias = reinterpret_cast<const float*>(bp->wp(bi));
+        a.condp = nullptr;
+        a.cond_rate = 256;
+        a.out = bp->act(h.off);
+        a.stats = bp->statp(h.stats_off);
+        a.C = base;
+        a.T = r.Lbase;
+        a.ntiles = ntiles_of(r.Lbase);
+        return launch_in_conv(a, r.B, prec, r.st);
+      });
+    }
+    b.tap("in_conv", h);
+    for (auto& s : blocks) {
+      TensorH o = b.resblock(s.prefix, s, {h}, false, 0, 0, 0);
+      b.release(h);
+      h = o;
+      b.tap(s.prefix, h);
+    }
+    const int cur = 8 * base;
+    const size_t ss = b.alloc_ss(cur);
+    b.add_gn({h}, "out.0.0", false, 0, 0, 0, ss);
+    TensorH o = b.new_tensor(c.out_channels, 8, true, false);
+    PackedConv pk;
+    Builder::SegSpec g{h, 0, cur, 3, 1, RESIZE_NONE, true, ss, cur, 0, 0};
+    g.w_off = pk.append(b.P("out.1.weight"), c.out_channels, cur, 3, 0, cur);
+    const float* bb = b.P("out.1.bias");
+    b.add_conv({g}, pk, std::vector<float>(bb, bb + c.out_channels), c.out_channels, o, nullptr, 0);
+    const int OC = c.out_channels;
+    m->ops.push_back([=](const RunCtx& r) -> int { return launch_ntc_to_nct(bp->act(o.off), r.out, r.B, OC, r.Lbase >> 8, 0, r.st); });
+  }
+
+  // ---- lay out the arena and upload the weights ------------------------------------------
+  m->act_bytes = (b.act_high + 255) & ~(size_t)255;
+  m->stats_off = m->act_bytes;
+  m->stats_floats = b.stats_floats;
+  m->ss_off = (m->stats_off + b.stats_floats * 4 + 255) & ~(size_t)255;
+  m->ss_floats = b.ss_floats;
+  m->misc_off = (m->ss_off + b.ss_floats * 4 + 255) & ~(size_t)255;
+  m->misc_floats = b.misc_floats;
+  m->arena_bytes = m->misc_off + b.misc_floats * 4 + 256;
+  m->weights_bytes = b.blob.data.size() + 256;
+  VQVS_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_weights), m->weights_bytes));
+  VQVS_HIP(hipMemcpy(m->d_weights, b.blob.data.data(), b.blob.data.size(), hipMemcpyHostToDevice));
+  VQVS_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_arena), m->arena_bytes));
+  VQVS_HIP(hipMemset(m->d_arena, 0, m->arena_bytes));
+  b.blob.data.clear();
+  b.blob.data.shrink_to_fit();
+  return 0;
+}
+
+int run_model(vqvs_model* m, const RunCtx& ctx) {
+  for (auto& op : m->ops)
+    if (int e = op(ctx)) return e;
+  m->last_B = ctx.B;
+  m->last_L = ctx.Lbase;
+  return 0;
+}
+
+}  // namespace vqvs

@@ -1,0 +1,337 @@
+"""
+UNetPredictor / UNetEncoder facades backed by the gfx950 library.
+
+The modules below are *parameter containers*: they register parameters under exactly the
+reference's state-dict names (reference vq_voice_swap/models/unet.py:16-116, 187-227,
+248-305; key list in SURVEY.md 8b) so checkpoints load unchanged, but their `forward`
+does not run torch ops -- it hands device pointers to `libvqvs_hip.so`
+(`vqvs_unet_forward` / `vqvs_encoder_forward`), which runs the fused HIP schedule.
+"""
+
+from __future__ import annotations
+
+import functools
+import os
+from typing import Callable, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _native
+
+CHANNEL_MULT = (1, 1, 2, 2, 2, 4, 4, 8, 8)
+MIDDLE_DILATIONS = (4, 8, 16, 32)
+
+
+def default_precision() -> str:
+    return os.environ.get("VQVS_PRECISION", "fp32")
+
+
+def _groups(ch: int) -> int:
+    g = 32
+    while ch % g:
+        g //= 2
+    return g
+
+
+def _scaled(mod: nn.Module, s: float) -> nn.Module:
+    with torch.no_grad():
+        for p in mod.parameters():
+            p.mul_(s)
+    return mod
+
+
+class _Slot(nn.Module):
+    """Parameter-free placeholder that keeps nn.Sequential indices aligned with the
+    reference's module layout (activations, resizes and dropout own no tensors)."""
+
+    def forward(self, x):  # pragma: no cover - containers are never called
+        return x
+
+
+def _seq(*mods: Optional[nn.Module]) -> nn.Sequential:
+    return nn.Sequential(*[m if m is not None else _Slot() for m in mods])
+
+
+class ResBlock(nn.Module):
+    """Parameters of one residual block: pre_cond.{0.0,2,3}, cond_layers.1, post_cond.{1|2}, skip.1."""
+
+    def __init__(self, channels: int, emb_channels: Optional[int] = None, out_channels: Optional[int] = None,
+                 scale_factor: float = 1.0, dilation: int = 2, dropout: float = 0.0):
+        super().__init__()
+        self.channels = channels
+        self.emb_channels = emb_channels
+        self.out_channels = out_channels or channels
+        self.scale_factor = scale_factor
+        self.dilation = dilation
+        self.dropout = dropout
+        co = self.out_channels
+        self.skip = _seq(None, nn.Conv1d(channels, co, 1) if channels != co else None)
+        if emb_channels:
+            self.cond_layers = _seq(None, _scaled(nn.Linear(emb_channels, 2 * co), 0.1))
+        self.pre_cond = _seq(_seq(nn.GroupNorm(_groups(channels), channels), None), None,
+                             nn.Conv1d(channels, co, 3, padding=1), nn.GroupNorm(_groups(co), co))
+        conv2 = _scaled(nn.Conv1d(co, co, 3, padding=dilation, dilation=dilation), 0.0)
+        self.post_cond = _seq(None, None, conv2) if dropout else _seq(None, conv2)
+
+
+class _NativeModule(nn.Module):
+    """Shared handle management: the device handle is (re)built lazily from the current
+    parameters and dropped whenever they may have changed."""
+
+    def __init__(self):
+        super().__init__()
+        self._handle = None
+        self._handle_key = None
+        self.precision = default_precision()
+        self.debug_taps = False
+
+    def set_precision(self, precision: str):
+        if precision not in _native.PRECISIONS:
+            raise ValueError(f"unknown precision {precision!r}; use 'fp32' or 'bf16'")
+        self.precision = precision
+        self.invalidate()
+        return self
+
+    def invalidate(self):
+        if self._handle is not None:
+            self._handle.close()
+        self._handle = None
+        self._handle_key = None
+
+    def _apply(self, fn, *a, **k):
+        self.invalidate()
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self.invalidate()
+        return super().load_state_dict(*a, **k)
+
+    def _load_from_state_dict(self, *a, **k):
+        self.invalidate()
+        return super()._load_from_state_dict(*a, **k)
+
+    def _cfg(self) -> _native.Cfg:
+        raise NotImplementedError
+
+    def handle(self, device: torch.device, B: int, T: int) -> _native.Handle:
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        key = (idx, self.precision, bool(self.debug_taps))
+        h = self._handle
+        if h is not None and self._handle_key == key and h.cfg.max_batch >= B and h.cfg.max_T >= T:
+            return h
+        if h is not None:
+            B = max(B, h.cfg.max_batch) if self._handle_key == key else B
+            T = max(T, h.cfg.max_T) if self._handle_key == key else T
+            self.invalidate()
+        cfg = self._cfg()
+        cfg.precision = _native.PRECISIONS[self.precision]
+        cfg.max_batch = B
+        cfg.max_T = T
+        cfg.debug_taps = 1 if self.debug_taps else 0
+        torch.cuda.synchronize(idx)
+        self._handle = _native.Handle(cfg, self.state_dict(), "", idx)
+        self._handle_key = key
+        return self._handle
+
+
+class UNetPredictor(_NativeModule):
+    def __init__(self, base_channels: int, channel_mult: Tuple[int, ...] = CHANNEL_MULT,
+                 middle_dilations: Tuple[int, ...] = MIDDLE_DILATIONS, depth_mult: int = 2,
+                 cond_channels: Optional[int] = None, num_labels: Optional[int] = None,
+                 in_channels: int = 1, out_channels: int = 1, dropout: float = 0.0):
+        super().__init__()
+        if tuple(channel_mult) != CHANNEL_MULT or tuple(middle_dilations) != MIDDLE_DILATIONS or depth_mult != 2:
+            raise ValueError("the gfx950 library implements the reference's default UNet topology only")
+        self.base_channels = base_channels
+        self.channel_mult = tuple(channel_mult)
+        self.middle_dilations = tuple(middle_dilations)
+        self.depth_mult = depth_mult
+        self.cond_channels = cond_channels
+        self.num_labels = num_labels
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.dropout = dropout
+
+        C = base_channels
+        E = 4 * C
+        self.time_embed = nn.Module()
+        self.time_embed.proj = nn.Linear(E, E)
+        self.time_embed.channels = E
+        self.time_embed_extra = _seq(None, nn.Linear(E, E))
+        if num_labels is not None:
+            self.class_embed = nn.Embedding(num_labels, E)
+        if cond_channels is not None:
+            self.cond_proj = nn.Conv1d(cond_channels, C, 3, padding=1)
+        self.in_conv = nn.Conv1d(in_channels, C, 3, padding=1)
+
+        down, stack, cur = [], [C], C
+        last = len(channel_mult) - 1
+        for depth, mult in enumerate(channel_mult):
+            for _ in range(depth_mult):
+                down.append(ResBlock(cur, E, mult * C, dropout=dropout))
+                cur = mult * C
+                stack.append(cur)
+            if depth != last:
+                down.append(ResBlock(cur, E, scale_factor=0.5, dropout=dropout))
+                stack.append(cur)
+        self.down_blocks = nn.ModuleList(down)
+        self.middle_blocks = nn.ModuleList([ResBlock(cur, E, dilation=d, dropout=dropout) for d in middle_dilations])
+        up = []
+        for depth in range(last, -1, -1):
+            mult = channel_mult[depth]
+            for _ in range(depth_mult + 1):
+                up.append(ResBlock(cur + stack.pop(), E, mult * C, dropout=dropout))
+                cur = mult * C
+            if depth:
+                up.append(ResBlock(cur, E, scale_factor=2.0, dropout=dropout))
+        self.up_blocks = nn.ModuleList(up)
+        self.out = _seq(_seq(nn.GroupNorm(_groups(C), C), None), nn.Conv1d(C, out_channels, 3, padding=1))
+
+    def _cfg(self) -> _native.Cfg:
+        cfg = _native.Cfg()
+        cfg.kind = _native.KIND_PREDICTOR
+        cfg.base_channels = self.base_channels
+        cfg.in_channels = self.in_channels
+        cfg.out_channels = self.out_channels
+        cfg.cond_channels = self.cond_channels or 0
+        cfg.num_labels = self.num_labels or 0
+        cfg.reserved[0] = 1 if self.dropout else 0
+        return cfg
+
+    def forward(self, x: torch.Tensor, ts: torch.Tensor, cond: Optional[torch.Tensor] = None,
+                labels: Optional[torch.Tensor] = None, use_checkpoint: bool = False) -> torch.Tensor:
+        assert (labels is None) == (self.num_labels is None), "must provide labels if and only if model is class conditional"
+        assert (cond is None) == (self.cond_channels is None), "must provide cond sequence if and only if model is conditional"
+        _native.require_cuda(x, ts, cond, labels)
+        if x.dim() != 3 or x.shape[1] != self.in_channels:
+            raise ValueError(f"expected x of shape [N, {self.in_channels}, T], got {tuple(x.shape)}")
+        B, _, T = x.shape
+        x = x.detach().to(torch.float32).contiguous()
+        ts = ts.detach().to(device=x.device, dtype=torch.float32).contiguous()
+        if ts.shape != (B,):
+            raise ValueError(f"expected ts of shape [{B}], got {tuple(ts.shape)}")
+        if cond is not None:
+            cond = cond.detach().to(torch.float32).contiguous()
+            if tuple(cond.shape) != (B, self.cond_channels, T // 256):
+                raise ValueError(f"expected cond of shape {(B, self.cond_channels, T // 256)}, got {tuple(cond.shape)}")
+        if labels is not None:
+            labels = labels.detach().to(device=x.device, dtype=torch.int64).contiguous()
+        h = self.handle(x.device, B, T)
+        out = torch.empty(B, self.out_channels, T, device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _native.check(_native.lib().vqvs_unet_forward(
+                h.ptr, x.data_ptr(), ts.data_ptr(), _native._ptr(cond), _native._ptr(labels), out.data_ptr(), B, T,
+                _native._stream_ptr()))
+        return out
+
+    def condition(self, **kwargs) -> Callable:
+        return functools.partial(self, **kwargs)
+
+    def add_labels(self, n: int, end: bool = True):
+        assert self.num_labels is not None
+        old = self.class_embed.weight.detach()
+        count = self.num_labels
+        self.num_labels += n
+        self.class_embed = nn.Embedding(self.num_labels, old.shape[-1]).to(old.device)
+        with torch.no_grad():
+            if end:
+                self.class_embed.weight[:count].copy_(old)
+            else:
+                self.class_embed.weight[n:].copy_(old)
+        self.invalidate()
+
+    def label_parameters(self) -> List[nn.Parameter]:
+        assert self.num_labels is not None
+        return list(self.class_embed.parameters())
+
+    @property
+    def downsample_rate(self) -> int:
+        return 2 ** (len(self.channel_mult) - 1)
+
+
+class UNetEncoder(_NativeModule):
+    def __init__(self, base_channels: int, channel_mult: Tuple[int, ...] = CHANNEL_MULT, out_dilations: Tuple[int, ...] = (),
+                 depth_mult: int = 2, in_channels: int = 1, out_channels: int = 512):
+        super().__init__()
+        if tuple(channel_mult) != CHANNEL_MULT or tuple(out_dilations) or depth_mult != 2:
+            raise ValueError("the gfx950 library implements the reference's default UNetEncoder topology only")
+        self.base_channels = base_channels
+        self.channel_mult = tuple(channel_mult)
+        self.depth_mult = depth_mult
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        C = base_channels
+        self.in_conv = nn.Conv1d(in_channels, C, 3, padding=1)
+        blocks, cur = [], C
+        last = len(channel_mult) - 1
+        for depth, mult in enumerate(channel_mult):
+            for _ in range(depth_mult):
+                blocks.append(ResBlock(cur, None, mult * C))
+                cur = mult * C
+            if depth != last:
+                blocks.append(ResBlock(cur, None, scale_factor=0.5))
+        self.blocks = nn.ModuleList(blocks)
+        self.out = _seq(_seq(nn.GroupNorm(_groups(cur), cur), None), nn.Conv1d(cur, out_channels, 3, padding=1))
+
+    def _cfg(self) -> _native.Cfg:
+        cfg = _native.Cfg()
+        cfg.kind = _native.KIND_ENCODER
+        cfg.base_channels = self.base_channels
+        cfg.in_channels = self.in_channels
+        cfg.out_channels = self.out_channels
+        return cfg
+
+    def forward(self, x: torch.Tensor, use_checkpoint: bool = False) -> torch.Tensor:
+        _native.require_cuda(x)
+        if x.dim() != 3 or x.shape[1] != self.in_channels:
+            raise ValueError(f"expected x of shape [N, {self.in_channels}, T], got {tuple(x.shape)}")
+        B, _, T = x.shape
+        x = x.detach().to(torch.float32).contiguous()
+        h = self.handle(x.device, B, T)
+        z = torch.empty(B, self.out_channels, T // 256, device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _native.check(_native.lib().vqvs_encoder_forward(h.ptr, x.data_ptr(), z.data_ptr(), B, T, _native._stream_ptr()))
+        return z
+
+    @property
+    def downsample_rate(self) -> int:
+        return 2 ** (len(self.channel_mult) - 1)
+
+
+class ResBlockModule(_NativeModule):
+    """A single residual block behind `vqvs_resblock_forward` (unit-test granularity)."""
+
+    def __init__(self, channels: int, emb_channels: Optional[int] = None, out_channels: Optional[int] = None,
+                 scale_factor: float = 1.0, dilation: int = 2):
+        super().__init__()
+        self.block = ResBlock(channels, emb_channels, out_channels, scale_factor, dilation)
+
+    def state_dict(self, *a, **k):
+        return self.block.state_dict(*a, **k)
+
+    def _cfg(self) -> _native.Cfg:
+        b = self.block
+        cfg = _native.Cfg()
+        cfg.kind = _native.KIND_RESBLOCK
+        cfg.base_channels = 32
+        cfg.in_channels = 1
+        cfg.rb_cin, cfg.rb_cout = b.channels, b.out_channels
+        cfg.rb_resize = 0 if b.scale_factor == 1.0 else (1 if b.scale_factor < 1.0 else 2)
+        cfg.rb_dilation = b.dilation
+        cfg.rb_emb_channels = b.emb_channels or 0
+        return cfg
+
+    def forward(self, x: torch.Tensor, emb: Optional[torch.Tensor] = None) -> torch.Tensor:
+        _native.require_cuda(x, emb)
+        B, _, L = x.shape
+        x = x.detach().to(torch.float32).contiguous()
+        emb = None if emb is None else emb.detach().to(torch.float32).contiguous()
+        h = self.handle(x.device, B, L)
+        b = self.block
+        Lo = L if b.scale_factor == 1.0 else (L // 2 if b.scale_factor < 1.0 else L * 2)
+        y = torch.empty(B, b.out_channels, Lo, device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _native.check(_native.lib().vqvs_resblock_forward(h.ptr, x.data_ptr(), _native._ptr(emb), y.data_ptr(), B, L,
+                                                             _native._stream_ptr()))
+        return y

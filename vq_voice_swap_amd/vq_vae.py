@@ -1,0 +1,87 @@
+"""
+VQVAE facade: UNet encoder + VQ + conditional diffusion decoder
+(reference vq_voice_swap/vq_vae.py:10-240).  encode / decode keep the reference's
+signatures; every stage runs in libvqvs_hip.so.
+"""
+
+from __future__ import annotations
+
+from typing import Any, Dict, Optional
+
+import torch
+
+from .diffusion import randn_clips
+from .diffusion_model import DiffusionModel
+from .unet import UNetEncoder
+from .vq import VQ
+
+
+def make_encoder(enc_name: str, base_channels: int = 32, cond_mult: int = 16):
+    if enc_name == "unet":
+        return UNetEncoder(base_channels=base_channels, out_channels=base_channels * cond_mult)
+    raise ValueError(f"encoder {enc_name!r} is outside the accelerated hot path (SURVEY.md section 2a); only 'unet' is built")
+
+
+class VQVAE(DiffusionModel):
+    def __init__(self, base_channels: int, enc_name: str = "unet", cond_mult: int = 16, dictionary_size: int = 512, **kwargs):
+        encoder = make_encoder(enc_name, base_channels=base_channels, cond_mult=cond_mult)
+        kwargs["cond_channels"] = base_channels * cond_mult
+        super().__init__(base_channels=base_channels, **kwargs)
+        self.enc_name = enc_name
+        self.cond_mult = cond_mult
+        self.dictionary_size = dictionary_size
+        self.encoder = encoder
+        self.vq = VQ(self.cond_channels, dictionary_size)
+
+    def set_precision(self, precision: str):
+        self.predictor.set_precision(precision)
+        self.encoder.set_precision(precision)
+        return self
+
+    def encode(self, inputs: torch.Tensor) -> torch.Tensor:
+        """[N,1,T] waveform -> [N,T/256] int64 codes (vq_vae.py:82-90)."""
+        with torch.no_grad():
+            return self.vq.encode(self.encoder(inputs))
+
+    def decode(self, codes: torch.Tensor, labels: Optional[torch.Tensor] = None, steps: int = 100, progress: bool = False,
+               constrain: bool = False, enc_pred=None, enc_pred_scale: float = 1.0, x_T: Optional[torch.Tensor] = None,
+               **kwargs) -> torch.Tensor:
+        """codes [N,T1] int or [N,C,T1] float -> [N,1,T1*256] waveform (vq_vae.py:92-145)."""
+        if codes.dim() == 2:
+            cond_seq = self.vq.embed(codes)
+        elif codes.dim() == 3:
+            cond_seq = codes
+        else:
+            raise ValueError(f"unsupported codes shape: {codes.shape}")
+        cond_fn = None
+        if enc_pred is not None:
+            targets = self.vq.encode(cond_seq)
+
+            def cond_fn(x, ts):
+                with torch.enable_grad():
+                    xg = x.detach().clone().requires_grad_(True)
+                    losses = enc_pred.losses(xg, ts, targets) * targets.shape[-1]
+                    grads = torch.autograd.grad(losses.sum(), xg)[0]
+                return grads * enc_pred_scale * -1
+
+        T = codes.shape[-1] * self.encoder.downsample_rate
+        seed = kwargs.pop("seed", None)
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        if x_T is None:
+            x_T = randn_clips(codes.shape[0], T, codes.device, seed, kwargs.get("clip_offset", 0))
+        return self.diffusion.ddpm_sample(
+            x_T, lambda xs, ts, **kw: self.predictor(xs, ts, cond=cond_seq, labels=labels, **kw),
+            steps=steps, progress=progress, constrain=constrain, cond_fn=cond_fn, seed=seed, **kwargs)
+
+    @property
+    def downsample_rate(self) -> int:
+        import math
+
+        a, b = self.predictor.downsample_rate, self.encoder.downsample_rate
+        return a * b // math.gcd(a, b)
+
+    def save_kwargs(self) -> Dict[str, Any]:
+        res = super().save_kwargs()
+        res.update(dict(enc_name=self.enc_name, cond_mult=self.cond_mult, dictionary_size=self.dictionary_size))
+        return res
