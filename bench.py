@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""
+Headline benchmark: audio clips/sec, unet64 50-step DDPM on 4 s @ 16 kHz waveforms (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch: `--batch` clips per GPU (default 64, i.e.
+BASELINE config 3's 512 clips over 8 GPUs) taken from x_T to x_0 through `--sample-steps` (50) DDPM
+iterations of the unet64 predictor, then gathered on rank 0.  x_T is generated on the GPU before the
+timed region (inputs resident in HBM); weights are the deterministic synthetic initialiser.
+
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline     - the dominant kernel (fused MFMA conv): algorithmic bytes of all its launches in one
+                 forward / their summed duration, measured live with hipEvents on the launch stream.
+  cpu_baseline - the CPU oracle (oracle/ref_cpu.py, stock torch fp32 on the host cores) on a bounded
+                 sample of the same workload, extrapolated to 50 steps.  Reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="unet64", choices=["unet32", "unet64"])
+    ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step")
+    ap.add_argument("--sample-steps", type=int, default=50)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--schedule", default="t**2", choices=["t", "t**2"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--T", type=int, default=64000)
+    return ap.parse_args()
+
+
+def cpu_baseline(base: int, T: int, sample_steps: int):
+    """Time the oracle on the host: `nb` clips x `ns` DDPM steps, extrapolated linearly to `sample_steps`."""
+    from oracle import ref_cpu
+    from vq_voice_swap_amd.det_init import det_tensor
+    from vq_voice_swap_amd import _native
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = _native.Cfg()
+    cfg.kind, cfg.base_channels, cfg.in_channels, cfg.out_channels = 0, base, 1, 1
+    sd = {"predictor." + n: det_tensor("predictor." + n, s) for n, s in _native.param_table(cfg)}
+    nb, ns = (4, 2) if base == 64 else (4, 4)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(nb, 1, T, generator=g)
+    noises = [torch.randn(nb, 1, T, generator=g) for _ in range(ns)]
+    pred = lambda a, b: ref_cpu.unet_predictor(sd, base, a, b)  # noqa: E731
+    with torch.no_grad():
+        pred(x[:1], torch.tensor([0.5]))  # warm the thread pool
+        t0 = time.time()
+        ref_cpu.ddpm_sample("exp", x, pred, ns, noises, constrain=True)
+        dt = time.time() - t0
+    clips_per_s = nb / (dt * sample_steps / ns)
+    return {"value": clips_per_s, "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/ref_cpu.py (torch fp32 CPU), unet{base}, {nb} clips x {ns} DDPM steps at T={T} in {dt:.1f}s, "
+                      f"extrapolated x{sample_steps}/{ns} steps"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if a.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    n_gpus = world
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from vq_voice_swap_amd import DiffusionModel, randn_clips
+    from vq_voice_swap_amd.det_init import det_init_
+    from vq_voice_swap_amd.sampler import gather_clips, shard_range
+
+    base = 64 if a.model == "unet64" else 32
+    model = DiffusionModel("unet", base)
+    det_init_(model.state_dict().items())
+    model.eval()
+    model.set_precision(a.precision)
+    tmap = (lambda t: t ** 2) if a.schedule == "t**2" else None
+    n_total = a.batch * n_gpus
+    begin, end = shard_range(n_total, rank, n_gpus)
+    seed = 1234
+
+    def one_step(step_id: int):
+        x_T = randn_clips(end - begin, a.T, dev, seed + step_id, clip_offset=begin)
+        torch.cuda.synchronize()
+        return x_T
+
+    def run(x_T, step_id):
+        x0 = model.diffusion.ddpm_sample(x_T, model.predictor, a.sample_steps, constrain=True, schedule=tmap,
+                                         seed=seed + step_id, clip_offset=begin)
+        return gather_clips(x0, n_total, a.T)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    for w in range(a.warmup):
+        run(one_step(w), w)
+    inputs = [one_step(100 + k) for k in range(a.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    out = None
+    for k in range(a.steps):
+        out = run(inputs[k], 100 + k)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        assert out is not None and out.shape == (n_total, 1, a.T) and bool(torch.isfinite(out).all())
+
+    # ---- live per-kernel timing of one forward (hipEvents on the launch stream), rank 0 ----
+    roof = None
+    extra = {}
+    if rank == 0:
+        h = model.predictor.handle(dev, end - begin, a.T)
+        B = end - begin
+        x = inputs[0]
+        ts = torch.full((B,), 0.5, device=dev)
+        h.set_profiling(True)
+        per_kind = {}
+        reps = 3
+        for _ in range(reps):
+            model.predictor(x, ts)
+            ms = h.profile_read()
+            for (kind, _by, _fl), t in zip(h.op_info(B, a.T), ms):
+                d = per_kind.setdefault(kind, dict(ms=0.0, bytes=0, flops=0, launches=0))
+                d["ms"] += t / reps
+        info = h.op_info(B, a.T)
+        for kind, by, fl in info:
+            per_kind[kind]["bytes"] += by
+            per_kind[kind]["flops"] += fl
+            per_kind[kind]["launches"] += 1
+        h.set_profiling(False)
+        conv = per_kind["conv"]
+        fwd_ms = sum(d["ms"] for d in per_kind.values())
+        ach = conv["bytes"] / (conv["ms"] * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                "kernel": "conv_mfma_kernel", "launches_per_forward": conv["launches"],
+                "avg_launch_us": round(conv["ms"] * 1e3 / conv["launches"], 2),
+                "algorithmic_bytes_per_forward": conv["bytes"],
+                "mfma_tflops": round(conv["flops"] / (conv["ms"] * 1e-3) / 1e12, 1)}
+        model_bytes = h.model_bytes(B, a.T)
+        extra = {
+            "forward_ms_event_sum": round(fwd_ms, 3),
+            "kernel_ms_per_forward": {k: round(v["ms"], 3) for k, v in sorted(per_kind.items(), key=lambda kv: -kv[1]["ms"])},
+            "model_bytes_per_forward": model_bytes,
+            "model_flops_per_forward": h.flops(B, a.T),
+            "e2e_hbm_frac": round(model_bytes * a.sample_steps * a.steps * n_gpus / dt / 1e9 / (HBM_PEAK_GBPS * n_gpus), 4),
+            "device_mem_GB": round(h.device_bytes() / 2 ** 30, 2),
+        }
+
+    cpu = None
+    if rank == 0 and not a.no_cpu_baseline and n_gpus == 1:
+        cpu = cpu_baseline(base, a.T, a.sample_steps)
+
+    if rank == 0:
+        clips = n_total * a.steps
+        line = {
+            "metric": "audio clips/sec (whole node), unet64 50-step DDPM on 4s@16kHz waveforms",
+            "value": round(clips / dt, 3),
+            "unit": "clips/s",
+            "n_gpus": n_gpus,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 2),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": a.precision,
+            "data": "synthetic (x_T ~ N(0,1) from the counter-based generator; deterministic synthetic weights)",
+            "config": {"workload": f"{a.model} {a.sample_steps}-step DDPM (constrain, schedule {a.schedule}), "
+                                   f"{a.batch} clips/GPU x {n_gpus} GPU of T={a.T}",
+                       "global_batch": n_total, "parallelism": f"clips sharded over {n_gpus} GPU(s), gather to rank 0"},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        line.update(extra)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

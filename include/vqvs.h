@@ -135,6 +135,13 @@ int vqvs_forward_kernel_count(const vqvs_model* m);
 int64_t vqvs_forward_model_bytes(const vqvs_model* m, int B, int T);
 int64_t vqvs_forward_flops(const vqvs_model* m, int B, int T);
 
+/* live per-kernel timing: when on, every forward brackets each enqueued kernel with hipEvents on
+ * the launch stream; vqvs_profile_read returns the elapsed ms of each op of the last forward and
+ * vqvs_op_info its kind ("conv", "gn_prepare", ...) and algorithmic bytes / flops for (B, T). */
+int vqvs_set_profiling(vqvs_model* m, int on);
+int vqvs_op_info(const vqvs_model* m, int i, char* kind_out, int kind_cap, int64_t* bytes_out, int64_t* flops_out, int B, int T);
+int vqvs_profile_read(vqvs_model* m, float* h_ms, int cap);
+
 const char* vqvs_last_error(void);
 const char* vqvs_version(void);
 

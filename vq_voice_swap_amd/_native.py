@@ -49,7 +49,7 @@ EXPORTS = [
     "vqvs_unet_forward", "vqvs_encoder_forward", "vqvs_resblock_forward", "vqvs_ddpm_step", "vqvs_ddpm_mean",
     "vqvs_ddpm_guided_eps", "vqvs_randn", "vqvs_vq_argmin", "vqvs_vq_embed", "vqvs_debug_tap_count",
     "vqvs_debug_tap_info", "vqvs_debug_read_tap", "vqvs_forward_kernel_count", "vqvs_forward_model_bytes",
-    "vqvs_forward_flops", "vqvs_last_error", "vqvs_version",
+    "vqvs_forward_flops", "vqvs_set_profiling", "vqvs_op_info", "vqvs_profile_read", "vqvs_last_error", "vqvs_version",
 ]
 
 _lib = None
@@ -109,6 +109,9 @@ def lib():
     L.vqvs_forward_model_bytes.restype = i64
     L.vqvs_forward_flops.argtypes = [vp, i32, i32]
     L.vqvs_forward_flops.restype = i64
+    L.vqvs_set_profiling.argtypes = [vp, i32]
+    L.vqvs_op_info.argtypes = [vp, i32, C.c_char_p, i32, C.POINTER(i64), C.POINTER(i64), i32, i32]
+    L.vqvs_profile_read.argtypes = [vp, vp, i32]
     _lib = L
     return L
 
@@ -208,6 +211,28 @@ class Handle:
 
     def flops(self, B: int, T: int) -> int:
         return int(lib().vqvs_forward_flops(self._h, B, T))
+
+    def set_profiling(self, on: bool) -> None:
+        check(lib().vqvs_set_profiling(self._h, 1 if on else 0))
+
+    def op_info(self, B: int, T: int) -> List[Tuple[str, int, int]]:
+        """(kind, algorithmic bytes, flops) of every kernel one forward enqueues."""
+        L = lib()
+        kind = C.create_string_buffer(64)
+        by, fl = C.c_int64(), C.c_int64()
+        out = []
+        for i in range(self.kernel_count()):
+            check(L.vqvs_op_info(self._h, i, kind, 64, C.byref(by), C.byref(fl), B, T))
+            out.append((kind.value.decode(), by.value, fl.value))
+        return out
+
+    def profile_read(self) -> List[float]:
+        n = self.kernel_count()
+        buf = (C.c_float * n)()
+        r = lib().vqvs_profile_read(self._h, buf, n)
+        if r < 0:
+            check(r)
+        return [float(buf[i]) for i in range(r)]
 
     def taps(self) -> List[Tuple[str, int, int]]:
         L = lib()

@@ -93,6 +93,7 @@ int vqvs_model_create(const vqvs_cfg* cfg, const float* const* h_params, int n_p
 
 void vqvs_model_destroy(vqvs_model* m) {
   if (!m) return;
+  for (auto e : m->events) (void)hipEventDestroy(e);
   if (m->d_weights) (void)hipFree(m->d_weights);
   if (m->d_arena) (void)hipFree(m->d_arena);
   delete m;
@@ -243,6 +244,41 @@ int64_t vqvs_forward_model_bytes(const vqvs_model* m, int B, int T) {
 int64_t vqvs_forward_flops(const vqvs_model* m, int B, int T) {
   if (!m) return 0;
   return (int64_t)(m->cost.flops * (double)T * (double)B);
+}
+
+}  // extern "C"
+
+// ---- profiling hooks (bench.py: live per-kernel timing with HIP events on the launch stream) ----
+extern "C" {
+
+int vqvs_set_profiling(vqvs_model* m, int on) {
+  if (!m) VQVS_FAIL(VQVS_ERR_ARG, "model is NULL");
+  m->profiling = on != 0;
+  return 0;
+}
+
+// kind / algorithmic bytes / flops of op i for the given problem size
+int vqvs_op_info(const vqvs_model* m, int i, char* kind_out, int kind_cap, int64_t* bytes_out, int64_t* flops_out, int B, int T) {
+  if (!m || i < 0 || i >= (int)m->meta.size()) VQVS_FAIL(VQVS_ERR_ARG, "bad op index");
+  const auto& mt = m->meta[i];
+  if (kind_out && kind_cap > 0) {
+    strncpy(kind_out, mt.kind.c_str(), kind_cap - 1);
+    kind_out[kind_cap - 1] = 0;
+  }
+  const double es = m->cfg.precision == VQVS_PREC_F32 ? 4.0 : 2.0;
+  if (bytes_out) *bytes_out = (int64_t)((mt.elems_T * es + mt.bytes_f32) * (double)T * (double)B);
+  if (flops_out) *flops_out = (int64_t)(mt.flops * (double)T * (double)B);
+  return 0;
+}
+
+// elapsed milliseconds of every op of the LAST profiled forward (synchronises the device)
+int vqvs_profile_read(vqvs_model* m, float* h_ms, int cap) {
+  if (!m || !h_ms) VQVS_FAIL(VQVS_ERR_ARG, "NULL argument");
+  if (m->events.size() != m->ops.size() + 1) VQVS_FAIL(VQVS_ERR_STATE, "no profiled forward has run");
+  VQVS_HIP(hipEventSynchronize(m->events.back()));
+  const int n = (int)m->ops.size() < cap ? (int)m->ops.size() : cap;
+  for (int i = 0; i < n; ++i) VQVS_HIP(hipEventElapsedTime(&h_ms[i], m->events[i], m->events[i + 1]));
+  return n;
 }
 
 }  // extern "C"

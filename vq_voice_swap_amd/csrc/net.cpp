@@ -210,6 +210,7 @@ class Builder {
     const int lshift = srcs[0].lshift;
     Builder* self = this;
     std::vector<TensorH> S = srcs;
+    m_->meta.push_back({"gn_prepare", 0, 0, 0});
     m_->ops.push_back([=](const RunCtx& c) -> int {
       GnArgs a{};
       const int L = shiftL(c.Lbase, lshift);
@@ -251,14 +252,16 @@ class Builder {
     const TensorH K = skip ? *skip : TensorH{};
     // cost
     double ktot = 0;
+    double conv_elems = 0, conv_f32 = 0;
     for (auto& s : segs) {
-      m_->cost.elems_T += s.C * lscale(s.t.lshift);
+      conv_elems += s.C * lscale(s.t.lshift);
       ktot += (double)s.C * s.ntaps;
     }
-    if (skip) m_->cost.elems_T += K.C * lscale(K.lshift);
-    if (out.f32) m_->cost.bytes_f32 += 4.0 * Cout * lscale(out.lshift);
-    else m_->cost.elems_T += Cout * lscale(out.lshift);
-    m_->cost.flops += 2.0 * Cout * ktot * lscale(out.lshift);
+    if (skip) conv_elems += K.C * lscale(K.lshift);
+    if (out.f32) conv_f32 += 4.0 * Cout * lscale(out.lshift);
+    else conv_elems += Cout * lscale(out.lshift);
+    const double conv_flops = 2.0 * Cout * ktot * lscale(out.lshift);
+    m_->meta.push_back({"conv", conv_elems, conv_f32, conv_flops});
     m_->ops.push_back([=](const RunCtx& c) -> int {
       ConvArgs a{};
       a.nseg = (int)S.size();
@@ -499,6 +502,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
     const int E = c.rb_emb_channels;
     TensorH x = b.new_tensor(c.rb_cin, 0, false, true);
     const int Cin = c.rb_cin;
+    m->meta.push_back({"nct_to_ntc", 0, 0, 0});
     m->ops.push_back([=](const RunCtx& r) -> int {
       return launch_nct_to_ntc(r.x, bp->act(x.off), bp->statp(x.stats_off), r.B, Cin, r.Lbase, ntiles_of(r.Lbase), prec, r.st);
     });
@@ -509,6 +513,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
       const size_t w_off = b.blob_f32("cond_layers.1.weight");
       const size_t bias_off = b.blob_f32("cond_layers.1.bias");
       const int R = 2 * c.rb_cout;
+      m->meta.push_back({"film", 0, 0, 0});
       m->ops.push_back([=](const RunCtx& r) -> int {
         if (!r.emb) VQVS_FAIL(VQVS_ERR_ARG, "resblock handle was built with an embedding; d_emb is NULL");
         if (int e = launch_gelu_rows(r.emb, bp->miscp(gemb), r.B * E, r.st)) return e;
@@ -519,6 +524,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
     }
     TensorH y = b.resblock("", s, {x}, E != 0, 0, 2 * c.rb_cout, film_misc);
     const int Cout = c.rb_cout;
+    m->meta.push_back({"ntc_to_nct", 0, 0, 0});
     m->ops.push_back([=](const RunCtx& r) -> int {
       return launch_ntc_to_nct(bp->act(y.off), r.out, r.B, Cout, shiftL(r.Lbase, y.lshift), prec, r.st);
     });
@@ -538,6 +544,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
     const size_t emb_off = b.alloc_misc((size_t)c.max_batch * E);
     const size_t gemb_off = b.alloc_misc((size_t)c.max_batch * E);
     const int NL = c.num_labels;
+    m->meta.push_back({"time_embed", 0, 0, 0});
     m->ops.push_back([=](const RunCtx& r) -> int {
       TimeEmbedArgs a{};
       a.ts = r.ts;
@@ -573,6 +580,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
     const size_t wall_off = b.blob.add(Wall.data(), Wall.size() * 4);
     const size_t ball_off = b.blob.add(ball.data(), ball.size() * 4);
     const size_t film_off = b.alloc_misc((size_t)c.max_batch * R);
+    m->meta.push_back({"film", 0, 0, 0});
     m->ops.push_back([=](const RunCtx& r) -> int {
       FilmArgs f{bp->miscp(gemb_off), reinterpret_cast<const float*>(bp->wp(wall_off)), reinterpret_cast<const float*>(bp->wp(ball_off)),
                  bp->miscp(film_off), E, R};
@@ -584,6 +592,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
     if (has_cond) {
       TensorH ct = b.new_tensor(c.cond_channels, 8, false, false);
       const int CC = c.cond_channels;
+      m->meta.push_back({"nct_to_ntc", 0, 0, 0});
       m->ops.push_back([=](const RunCtx& r) -> int {
         return launch_nct_to_ntc(r.cond, bp->act(ct.off), nullptr, r.B, CC, r.Lbase >> 8, 0, prec, r.st);
       });
@@ -600,8 +609,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
     {
       const size_t w = b.blob_f32("in_conv.weight"), bi = b.blob_f32("in_conv.bias");
       const TensorH cp = condp;
-      m->cost.bytes_f32 += 4.0;
-      m->cost.elems_T += base + (has_cond ? base / 256.0 : 0.0);
+      m->meta.push_back({"in_conv", base + (has_cond ? base / 256.0 : 0.0), 4.0, 0});
       m->ops.push_back([=](const RunCtx& r) -> int {
         InConvArgs a{};
         a.x = r.x;
@@ -661,8 +669,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
         for (int ci = 0; ci < base; ++ci) wt[k * base + ci] = W[ci * 3 + k];
       const size_t w = b.blob.add(wt.data(), wt.size() * 4);
       const float bias = b.P("out.1.bias")[0];
-      m->cost.elems_T += base;
-      m->cost.bytes_f32 += 4.0;
+      m->meta.push_back({"out_conv", (double)base, 4.0, 0});
       m->ops.push_back([=](const RunCtx& r) -> int {
         OutConvArgs a{};
         a.in = bp->act(h.off);
@@ -682,6 +689,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
       const float* bb = b.P("out.1.bias");
       b.add_conv({g}, pk, std::vector<float>(bb, bb + c.out_channels), c.out_channels, o, nullptr, 0);
       const int OC = c.out_channels;
+      m->meta.push_back({"ntc_to_nct", 0, 0, 0});
       m->ops.push_back([=](const RunCtx& r) -> int { return launch_ntc_to_nct(bp->act(o.off), r.out, r.B, OC, r.Lbase, 0, r.st); });
     }
   } else {  // encoder (unet.py:229-241)
@@ -690,8 +698,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
     TensorH h = b.new_tensor(base, 0, false, true);
     {
       const size_t w = b.blob_f32("in_conv.weight"), bi = b.blob_f32("in_conv.bias");
-      m->cost.bytes_f32 += 4.0;
-      m->cost.elems_T += base;
+      m->meta.push_back({"in_conv", (double)base, 4.0, 0});
       m->ops.push_back([=](const RunCtx& r) -> int {
         InConvArgs a{};
         a.x = r.x;
@@ -724,9 +731,15 @@ int build_model(vqvs_model* m, const float* const* hp) {
     const float* bb = b.P("out.1.bias");
     b.add_conv({g}, pk, std::vector<float>(bb, bb + c.out_channels), c.out_channels, o, nullptr, 0);
     const int OC = c.out_channels;
+    m->meta.push_back({"ntc_to_nct", 0, 0, 0});
     m->ops.push_back([=](const RunCtx& r) -> int { return launch_ntc_to_nct(bp->act(o.off), r.out, r.B, OC, r.Lbase >> 8, 0, r.st); });
   }
 
+  for (auto& mt : m->meta) {
+    m->cost.elems_T += mt.elems_T;
+    m->cost.bytes_f32 += mt.bytes_f32;
+    m->cost.flops += mt.flops;
+  }
   // ---- lay out the arena and upload the weights ------------------------------------------
   m->act_bytes = (b.act_high + 255) & ~(size_t)255;
   m->stats_off = m->act_bytes;
@@ -747,6 +760,21 @@ int build_model(vqvs_model* m, const float* const* hp) {
 }
 
 int run_model(vqvs_model* m, const RunCtx& ctx) {
+  if (m->profiling) {
+    if (m->events.size() != m->ops.size() + 1) {
+      for (auto e : m->events) (void)hipEventDestroy(e);
+      m->events.assign(m->ops.size() + 1, nullptr);
+      for (auto& e : m->events) VQVS_HIP(hipEventCreate(&e));
+    }
+    VQVS_HIP(hipEventRecord(m->events[0], ctx.st));
+    for (size_t i = 0; i < m->ops.size(); ++i) {
+      if (int e = m->ops[i](ctx)) return e;
+      VQVS_HIP(hipEventRecord(m->events[i + 1], ctx.st));
+    }
+    m->last_B = ctx.B;
+    m->last_L = ctx.Lbase;
+    return 0;
+  }
   for (auto& op : m->ops)
     if (int e = op(ctx)) return e;
   m->last_B = ctx.B;

@@ -66,6 +66,15 @@ struct vqvs_model {
   // arena regions
   size_t act_bytes = 0, stats_off = 0, stats_floats = 0, ss_off = 0, ss_floats = 0, misc_off = 0, misc_floats = 0;
   std::vector<std::function<int(const vqvs::RunCtx&)>> ops;
+  struct OpMeta {
+    std::string kind;      // "conv", "gn_prepare", "in_conv", ...
+    double elems_T = 0;    // algorithmic activation elements (storage type) per clip per unit of base length
+    double bytes_f32 = 0;  // float32 boundary bytes per clip per unit of base length
+    double flops = 0;      // per clip per unit of base length
+  };
+  std::vector<OpMeta> meta;  // parallel to ops
+  bool profiling = false;
+  std::vector<hipEvent_t> events;  // ops.size() + 1 when profiling
   std::vector<vqvs::TapDef> taps;
   // accounting (per clip, per unit of base length): elements moved / flops, as (coefficient, lshift) lists
   struct Cost {

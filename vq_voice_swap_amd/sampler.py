@@ -1,0 +1,95 @@
+"""
+Whole-job sampling: shard independent clips across ranks (one process per GPU), sample each
+shard with the HIP path, gather the finished waveforms on rank 0.
+
+The path shards embarrassingly: GroupNorm, the `constrain` mean and VQ are all
+per clip, so there is NO collective on the data path; the only communication is the final
+gather of [n_local,1,T] float32 shards (RCCL over xGMI when the backend is "nccl").  Noise and
+x_T are keyed by the GLOBAL clip index, so every clip is bit-identical whatever the GPU count.
+"""
+
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+
+
+def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous [begin, end) of rank's clips; the first n_total % world ranks get one extra."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world of {world}")
+    base, extra = divmod(n_total, world)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def _dist_info():
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def gather_clips(local: torch.Tensor, n_total: int, T: int) -> Optional[torch.Tensor]:
+    """Gather variable-size shards [n_local,1,T] to rank 0 in global clip order (None elsewhere)."""
+    import torch.distributed as dist
+
+    rank, world = _dist_info()
+    if world == 1:
+        return local
+    sizes = [shard_range(n_total, r, world) for r in range(world)]
+    n_max = max(e - b for b, e in sizes)
+    pad = local
+    if local.shape[0] < n_max:
+        pad = torch.cat([local, local.new_zeros(n_max - local.shape[0], 1, T)], dim=0)
+    pad = pad.contiguous()
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+    dist.gather(pad, bufs, dst=0)
+    if rank != 0:
+        return None
+    return torch.cat([bufs[r][: e - b] for r, (b, e) in enumerate(sizes)], dim=0)
+
+
+def sample_clips(
+    model,
+    n_total: int,
+    T: int,
+    steps: int,
+    seed: int,
+    *,
+    device=None,
+    constrain: bool = False,
+    sigma_large: bool = False,
+    schedule: Optional[Callable] = None,
+    labels: Optional[torch.Tensor] = None,
+    gather: bool = True,
+    sample_fn: Optional[Callable[[int, int, int], torch.Tensor]] = None,
+) -> Optional[torch.Tensor]:
+    """Sample `n_total` clips over all ranks.  `labels` (global, [n_total]) selects per-clip classes for a
+    class-conditional model (the counterpart of sample_diffusion.py:108-122).  `sample_fn(begin, end, seed)`
+    replaces the HIP sampler (used by the CPU gloo tests of the sharding logic)."""
+    rank, world = _dist_info()
+    begin, end = shard_range(n_total, rank, world)
+    n_local = end - begin
+    if sample_fn is not None:
+        local = sample_fn(begin, end, seed)
+    else:
+        from .diffusion import randn_clips
+
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        if n_local == 0:
+            local = torch.empty(0, 1, T, device=device)
+        else:
+            x_T = randn_clips(n_local, T, device, seed, clip_offset=begin)
+            pred = model.predictor
+            if labels is not None:
+                lab = labels[begin:end].to(device)
+                pred = lambda xs, ts, _p=model.predictor, _l=lab: _p(xs, ts, labels=_l)  # noqa: E731
+            local = model.diffusion.ddpm_sample(x_T, pred, steps, constrain=constrain, sigma_large=sigma_large,
+                                                schedule=schedule, seed=seed, clip_offset=begin)
+    if not gather:
+        return local
+    return gather_clips(local, n_total, T)
