@@ -1,0 +1,117 @@
+"""CPU-side checks: the C-ABI library loads and exports every declared symbol, the parameter table equals
+the reference's state-dict layout, checkpoints round-trip, error behaviour, sharding logic (gloo, world 2)."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from vq_voice_swap_amd import DiffusionModel, VQVAE, _native
+from vq_voice_swap_amd.sampler import shard_range
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(lib_built):
+    header = open(os.path.join(ROOT, "include", "vqvs.h")).read()
+    declared = set(re.findall(r"\b(vqvs_[a-z0-9_]+)\s*\(", header))
+    declared -= {"vqvs_model", "vqvs_cfg"}
+    assert declared, "no declarations found"
+    for sym in sorted(declared):
+        assert hasattr(lib_built, sym), f"libvqvs_hip.so does not export {sym}"
+    assert set(_native.EXPORTS) <= declared | {"vqvs_last_error", "vqvs_version"}
+    assert b"gfx950" in lib_built.vqvs_version()
+
+
+def test_param_table_is_the_reference_state_dict(lib_built):
+    m = DiffusionModel("unet", 32, num_labels=3, dropout=0.1)
+    sd = m.predictor.state_dict()
+    table = _native.param_table(m.predictor._cfg())
+    assert [n for n, _ in table] and set(n for n, _ in table) == set(sd.keys())
+    assert all(tuple(sd[n].shape) == s for n, s in table)
+    assert "down_blocks.0.post_cond.2.weight" in sd  # dropout checkpoints keep the conv at index 2 (unet.py:295-300)
+    v = VQVAE(base_channels=32, pred_name="unet", num_labels=5)
+    keys = list(v.state_dict().keys())
+    assert "vq.dictionary" in keys and "vq.usage_count" in keys and "encoder.blocks.25.pre_cond.2.weight" in keys
+    assert v.cond_channels == 512 and v.save_kwargs()["enc_name"] == "unet"
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    m = DiffusionModel("unet", 32, num_labels=4)
+    p = str(tmp_path / "m.pt")
+    m.save(p)
+    state = torch.load(p, map_location="cpu")
+    assert set(state.keys()) == {"kwargs", "state_dict"}  # reference format, base.py:74-82
+    m2 = DiffusionModel.load(p)
+    for (k1, v1), (k2, v2) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+    # old checkpoints stored dropout as a 1-tuple (diffusion_model.py:30-31)
+    assert DiffusionModel("unet", 32, dropout=(0.0,)).dropout == 0.0
+
+
+def test_errors_mirror_the_reference(lib_built):
+    m = DiffusionModel("unet", 32, num_labels=4)
+    x, ts = torch.zeros(1, 1, 256), torch.zeros(1)
+    with pytest.raises(AssertionError, match="must provide labels"):
+        m.predictor(x, ts)
+    with pytest.raises(AssertionError, match="must provide cond"):
+        m.predictor(x, ts, cond=torch.zeros(1, 512, 1), labels=torch.zeros(1).long())
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.predictor(x, ts, labels=torch.zeros(1).long())
+    with pytest.raises(ValueError, match="unknown schedule"):
+        DiffusionModel("unet", 32, schedule_name="nope")
+    with pytest.raises(ValueError, match="unknown predictor"):
+        DiffusionModel("nope", 32)
+    cfg = _native.Cfg()
+    cfg.kind, cfg.base_channels, cfg.in_channels, cfg.out_channels = 0, 48, 1, 1
+    with pytest.raises(ValueError):
+        _native.param_table(cfg) and _native.check(-1)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_native.NativeError, match="no CPU fallback"):
+        _native.lib()
+
+
+def test_shard_ranges_cover_exactly():
+    for n in (0, 1, 7, 64, 511, 512):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [e - b for b, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+from vq_voice_swap_amd.sampler import sample_clips, shard_range
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+T, n_total = 512, 5
+def fake(begin, end, seed):   # a "sampler" whose output depends only on the GLOBAL clip index
+    return torch.stack([torch.full((1, T), float(seed * 1000 + i)) for i in range(begin, end)]) if end > begin else torch.empty(0, 1, T)
+out = sample_clips(None, n_total, T, steps=3, seed=7, sample_fn=fake)
+if rank == 0:
+    assert out.shape == (n_total, 1, T), out.shape
+    assert [int(v) for v in out[:, 0, 0].tolist()] == [7000 + i for i in range(n_total)]
+    print("GATHER_OK")
+else:
+    assert out is None
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_gather_gloo(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29531", str(script)], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "GATHER_OK" in r.stdout

@@ -207,6 +207,8 @@ class UNetPredictor(_NativeModule):
         if x.dim() != 3 or x.shape[1] != self.in_channels:
             raise ValueError(f"expected x of shape [N, {self.in_channels}, T], got {tuple(x.shape)}")
         B, _, T = x.shape
+        if T % self.downsample_rate:
+            raise ValueError(f"T={T} is not a multiple of the UNet downsample rate {self.downsample_rate}")
         x = x.detach().to(torch.float32).contiguous()
         ts = ts.detach().to(device=x.device, dtype=torch.float32).contiguous()
         if ts.shape != (B,):
@@ -287,6 +289,8 @@ class UNetEncoder(_NativeModule):
         if x.dim() != 3 or x.shape[1] != self.in_channels:
             raise ValueError(f"expected x of shape [N, {self.in_channels}, T], got {tuple(x.shape)}")
         B, _, T = x.shape
+        if T % self.downsample_rate:
+            raise ValueError(f"T={T} is not a multiple of the UNet downsample rate {self.downsample_rate}")
         x = x.detach().to(torch.float32).contiguous()
         h = self.handle(x.device, B, T)
         z = torch.empty(B, self.out_channels, T // 256, device=x.device, dtype=torch.float32)
