@@ -140,6 +140,7 @@ int64_t vqvs_forward_flops(const vqvs_model* m, int B, int T);
  * vqvs_op_info its kind ("conv", "gn_prepare", ...) and algorithmic bytes / flops for (B, T). */
 int vqvs_set_profiling(vqvs_model* m, int on);
 int vqvs_op_info(const vqvs_model* m, int i, char* kind_out, int kind_cap, int64_t* bytes_out, int64_t* flops_out, int B, int T);
+int vqvs_op_desc(const vqvs_model* m, int i, char* out, int cap);
 int vqvs_profile_read(vqvs_model* m, float* h_ms, int cap);
 
 const char* vqvs_last_error(void);

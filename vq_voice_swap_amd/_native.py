@@ -49,7 +49,7 @@ EXPORTS = [
     "vqvs_unet_forward", "vqvs_encoder_forward", "vqvs_resblock_forward", "vqvs_ddpm_step", "vqvs_ddpm_mean",
     "vqvs_ddpm_guided_eps", "vqvs_randn", "vqvs_vq_argmin", "vqvs_vq_embed", "vqvs_debug_tap_count",
     "vqvs_debug_tap_info", "vqvs_debug_read_tap", "vqvs_forward_kernel_count", "vqvs_forward_model_bytes",
-    "vqvs_forward_flops", "vqvs_set_profiling", "vqvs_op_info", "vqvs_profile_read", "vqvs_last_error", "vqvs_version",
+    "vqvs_forward_flops", "vqvs_set_profiling", "vqvs_op_info", "vqvs_op_desc", "vqvs_profile_read", "vqvs_last_error", "vqvs_version",
 ]
 
 _lib = None
@@ -112,6 +112,7 @@ def lib():
     L.vqvs_set_profiling.argtypes = [vp, i32]
     L.vqvs_op_info.argtypes = [vp, i32, C.c_char_p, i32, C.POINTER(i64), C.POINTER(i64), i32, i32]
     L.vqvs_profile_read.argtypes = [vp, vp, i32]
+    L.vqvs_op_desc.argtypes = [vp, i32, C.c_char_p, i32]
     _lib = L
     return L
 
@@ -224,6 +225,14 @@ class Handle:
         for i in range(self.kernel_count()):
             check(L.vqvs_op_info(self._h, i, kind, 64, C.byref(by), C.byref(fl), B, T))
             out.append((kind.value.decode(), by.value, fl.value))
+        return out
+
+    def op_desc(self) -> List[str]:
+        buf = C.create_string_buffer(256)
+        out = []
+        for i in range(self.kernel_count()):
+            check(lib().vqvs_op_desc(self._h, i, buf, 256))
+            out.append(buf.value.decode())
         return out
 
     def profile_read(self) -> List[float]:

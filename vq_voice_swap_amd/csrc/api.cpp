@@ -271,6 +271,13 @@ int vqvs_op_info(const vqvs_model* m, int i, char* kind_out, int kind_cap, int64
   return 0;
 }
 
+int vqvs_op_desc(const vqvs_model* m, int i, char* out, int cap) {
+  if (!m || i < 0 || i >= (int)m->meta.size() || !out || cap < 1) VQVS_FAIL(VQVS_ERR_ARG, "bad argument");
+  strncpy(out, m->meta[i].desc.c_str(), cap - 1);
+  out[cap - 1] = 0;
+  return 0;
+}
+
 // elapsed milliseconds of every op of the LAST profiled forward (synchronises the device)
 int vqvs_profile_read(vqvs_model* m, float* h_ms, int cap) {
   if (!m || !h_ms) VQVS_FAIL(VQVS_ERR_ARG, "NULL argument");

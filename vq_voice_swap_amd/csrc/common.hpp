@@ -56,6 +56,56 @@ __device__ __forceinline__ float gelu_f(float v) {
   return 0.5f * v * (1.0f + copysignf(e, v));
 }
 
+// Packed-math variants (v_pk_fma_f32 / v_pk_mul_f32 process two floats per lane per issue; a plain
+// wave64 VALU instruction occupies the SIMD for 4 cycles on gfx950, so the prologue is written on
+// float2 throughout).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 splat2(float x) { return f32x2{x, x}; }
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// EXACT = true : the A&S 7.1.28 form above, packed (|gelu error| <= 8.7e-7) -- VQVS_PREC_F32.
+// EXACT = false: v * max(0, 0.5 + vc*P(vc^2)), vc = clamp(v, -4, 4), P = degree-6 minimax fit of
+//                (Phi(v) - 0.5)/v; max |gelu error| = 4.1e-4 on [-8, 8], below the bf16 rounding of
+//                the stored result (2^-9 relative) -- VQVS_PREC_BF16.  No transcendental.
+template <bool EXACT>
+__device__ __forceinline__ f32x2 gelu2(f32x2 v) {
+  if constexpr (EXACT) {
+    f32x2 z;
+    z[0] = fabsf(v[0]);
+    z[1] = fabsf(v[1]);
+    z = z * splat2(0.70710678118654752440f);
+    f32x2 p = fma2(splat2(0.0000430638f), z, splat2(0.0002765672f));
+    p = fma2(p, z, splat2(0.0001520143f));
+    p = fma2(p, z, splat2(0.0092705272f));
+    p = fma2(p, z, splat2(0.0422820123f));
+    p = fma2(p, z, splat2(0.0705230784f));
+    p = fma2(p, z, splat2(1.0f));
+    p = p * p;
+    p = p * p;
+    p = p * p;
+    p = p * p;
+    f32x2 e;
+    e[0] = copysignf(1.0f - __builtin_amdgcn_rcpf(p[0]), v[0]);
+    e[1] = copysignf(1.0f - __builtin_amdgcn_rcpf(p[1]), v[1]);
+    return (v * splat2(0.5f)) * (e + splat2(1.0f));
+  } else {
+    f32x2 vc;
+    vc[0] = __builtin_amdgcn_fmed3f(v[0], -4.0f, 4.0f);
+    vc[1] = __builtin_amdgcn_fmed3f(v[1], -4.0f, 4.0f);
+    const f32x2 w = vc * vc;
+    f32x2 p = fma2(splat2(2.81608722e-08f), w, splat2(-1.89188380e-06f));
+    p = fma2(p, w, splat2(5.41903041e-05f));
+    p = fma2(p, w, splat2(-8.78980255e-04f));
+    p = fma2(p, w, splat2(9.11294959e-03f));
+    p = fma2(p, w, splat2(-6.53883549e-02f));
+    p = fma2(p, w, splat2(3.98526915e-01f));
+    f32x2 ph = fma2(vc, p, splat2(0.5f));
+    ph[0] = fmaxf(ph[0], 0.f);
+    ph[1] = fmaxf(ph[1], 0.f);
+    return v * ph;
+  }
+}
+
 // element load/store of 8 consecutive channels as fp32, for both activation storage types
 template <typename T>
 struct Elem;

@@ -5,11 +5,16 @@
 //   workgroup  = 256 threads = 4 waves, output tile 256 time rows x CT channels (CT = 32*WN)
 //   wave       = 64 rows x CT channels = 2 x WN tiles of v_mfma_f32_32x32x16_bf16
 //   GEMM roles : A = activations (M = time), B = weights (N = output channel), so an
-//                accumulator lane owns ONE output channel -> channel statistics are in-lane.
+//                accumulator lane owns ONE output channel.
 //   K loop     : segment -> chunk of 32 input channels -> tap -> 2 k-steps of 16.
 //                One staged activation chunk (rows t0-d .. t0+255+d, 32 channels, prologue
 //                applied once) serves all three taps: the taps differ only in the LDS row a
 //                lane reads.
+//   pipeline   : the K loop is software-pipelined.  While the matrix cores work on chunk i
+//                (LDS buffer i&1) the global loads of chunk i+1 (raw activations, scale/shift,
+//                weights) are already in flight into registers; they are transformed
+//                (affine + GELU + bf16 split) and written to LDS buffer (i+1)&1 after the
+//                MFMAs.  One __syncthreads() per chunk.
 //   LDS rows are 64 B of bf16 padded to 80 B: a ds_read_b128 lane group then touches 16
 //                distinct 16-byte slots (5*r mod 16 is a bijection) -> conflict free.
 //   VQVS_PREC_F32: operands are split x = hi + lo in bf16 and the product is evaluated as
@@ -20,10 +25,12 @@ namespace vqvs {
 
 namespace {
 
-constexpr int TT = 256;          // time rows per workgroup (== STAT_TILE)
-constexpr int ROWB = 80;         // LDS bytes per 32-channel row (64 data + 16 pad)
-constexpr int ACT_ROWS = TT + 64;  // halo for dilation <= 32
-constexpr int ACT_BYTES = ACT_ROWS * ROWB;
+constexpr int TT = 256;   // time rows per workgroup (== STAT_TILE)
+constexpr int ROWB = 80;  // LDS bytes per 32-channel row (64 data + 16 pad)
+constexpr int NPF = 5;    // prefetched (row, octet) items per thread: covers 320 rows x 4 octets
+
+template <int HALO>
+constexpr int act_bytes() { return (TT + HALO) * ROWB; }
 
 template <bool X3>
 __device__ __forceinline__ void put_row(char* act_hi, char* act_lo, int off, f32x8 v) {
@@ -37,23 +44,54 @@ __device__ __forceinline__ void put_row(char* act_hi, char* act_lo, int off, f32
   }
 }
 
+template <bool EXACT>
 __device__ __forceinline__ f32x8 affine_gelu(f32x8 v, const f32x8& sc, const f32x8& sh) {
   f32x8 r;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) r[j] = gelu_f(fmaf(v[j], sc[j], sh[j]));
+  for (int j = 0; j < 8; j += 2) {
+    const f32x2 g = gelu2<EXACT>(fma2(f32x2{v[j], v[j + 1]}, f32x2{sc[j], sc[j + 1]}, f32x2{sh[j], sh[j + 1]}));
+    r[j] = g[0];
+    r[j + 1] = g[1];
+  }
   return r;
 }
 
-template <typename T, bool X3, int WN>
+// raw (untransformed) octet as it sits in HBM
+template <typename T> struct Raw8;
+template <> struct Raw8<float> {
+  f32x4 a, b;
+  __device__ __forceinline__ void load(const float* p) {
+    a = *reinterpret_cast<const f32x4*>(p);
+    b = *reinterpret_cast<const f32x4*>(p + 4);
+  }
+  __device__ __forceinline__ f32x8 get() const { return f32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
+};
+template <> struct Raw8<bf16_t> {
+  bf16x8 a;
+  __device__ __forceinline__ void load(const bf16_t* p) { a = *reinterpret_cast<const bf16x8*>(p); }
+  __device__ __forceinline__ f32x8 get() const { return __builtin_convertvector(a, f32x8); }
+};
+
+// everything a thread needs to know about one K iteration (segment, chunk)
+struct IterGeom {
+  int s, ch;        // segment, chunk
+  int ntaps, d;     // taps and dilation (0 for 1-tap)
+  int nrows;        // LDS rows to stage
+  int base_time;    // time index of LDS row 0 (in the staged resolution)
+  int row_bound;    // valid time range [0, row_bound)
+  bool up, avg, xform;
+};
+
+template <typename T, bool X3, int WN, int HALO>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   constexpr int WM = 2;
   constexpr int CT = WN * 32;
+  constexpr int ACT_BYTES = act_bytes<HALO>();
   constexpr int W_BYTES = 3 * CT * ROWB;
+  constexpr int NWV = (3 * CT * 4 + 255) / 256;  // 16-byte weight pieces per thread per chunk
+  constexpr int PLANES = X3 ? 2 : 1;
+  constexpr int BUF_BYTES = PLANES * (ACT_BYTES + W_BYTES);
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const act_hi = smem;
-  char* const act_lo = smem + ACT_BYTES;  // X3 only
-  char* const w_hi = smem + (X3 ? 2 : 1) * ACT_BYTES;
-  char* const w_lo = w_hi + W_BYTES;  // X3 only
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -61,6 +99,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   const int b = blockIdx.z;
   const int co0 = blockIdx.y * CT;
   const int t0 = blockIdx.x * TT;
+  const int oct = tid & 3;
+  const int l31 = lane & 31;
+  const int khalf = (lane >> 5) * 16;
 
   f32x16 acc[WM][WN];
 #pragma unroll
@@ -70,105 +111,176 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int l31 = lane & 31;
-  const int khalf = (lane >> 5) * 16;  // byte offset of this lane's 8-wide k slice within a 16-wide k-step
+  int niter = 0;
+  for (int s = 0; s < a.nseg; ++s) niter += a.seg[s].C >> 5;
 
-  for (int s = 0; s < a.nseg; ++s) {
+  auto geom = [&](int s, int ch) {
+    IterGeom g;
     const SegDesc& sg = a.seg[s];
-    const int ntaps = sg.ntaps;
-    const int d = (ntaps == 3) ? sg.dil : 0;
-    const int nchunks = sg.C >> 5;
-    const bool up = sg.resize == RESIZE_UP2;
-    const bool avg = sg.resize == RESIZE_AVG2;
-    const int nrows = up ? (TT / 2 + 2) : (TT + 2 * d);
-    const int base_time = up ? ((t0 >> 1) - 1) : (t0 - d);
-    const int row_bound = avg ? a.Lout : sg.Lsrc;  // valid range of the staged row's time index
-    const T* const src_b = reinterpret_cast<const T*>(sg.src) + (size_t)b * sg.Lsrc * sg.Csrc;
-    const bool xform = sg.ss != nullptr;
+    g.s = s;
+    g.ch = ch;
+    g.ntaps = sg.ntaps;
+    g.d = (sg.ntaps == 3) ? sg.dil : 0;
+    g.up = sg.resize == RESIZE_UP2;
+    g.avg = sg.resize == RESIZE_AVG2;
+    g.xform = sg.ss != nullptr;
+    g.nrows = g.up ? (TT / 2 + 2) : (TT + 2 * g.d);
+    g.base_time = g.up ? ((t0 >> 1) - 1) : (t0 - g.d);
+    g.row_bound = g.avg ? a.Lout : sg.Lsrc;
+    return g;
+  };
 
-    for (int ch = 0; ch < nchunks; ++ch) {
-      __syncthreads();  // all waves finished reading the previous chunk
-      // ---------------- stage activations (prologue fused) ----------------
-      {
-        const int oct = tid & 3;
-        const int cl = ch * 32 + oct * 8;
-        f32x8 sc, sh;
-        if (xform) {
-          const float2* p = sg.ss + (size_t)b * sg.ss_stride + sg.ss_c0 + cl;
+  // ---- prefetch registers -------------------------------------------------------------
+  Raw8<T> ra[NPF];
+  f32x4 rss[4];
+  bf16x8 rwh[NWV], rwl[NWV];
+  (void)rwl;
+
+  auto issue_loads = [&](const IterGeom& g) {
+    const SegDesc& sg = a.seg[g.s];
+    const int cl = g.ch * 32 + oct * 8;
+    if (g.xform) {
+      const float2* p = sg.ss + (size_t)b * sg.ss_stride + sg.ss_c0 + cl;
 #pragma unroll
-          for (int j = 0; j < 8; j += 2) {
-            const f32x4 q = *reinterpret_cast<const f32x4*>(p + j);
-            sc[j] = q[0]; sh[j] = q[1]; sc[j + 1] = q[2]; sh[j + 1] = q[3];
-          }
-        }
-        const T* const src_c = src_b + sg.c0 + cl;
-        for (int r = tid >> 2; r < nrows; r += 64) {
-          const int tm = base_time + r;
+      for (int j = 0; j < 4; ++j) rss[j] = *reinterpret_cast<const f32x4*>(p + 2 * j);
+    }
+    if (!g.avg) {
+      const T* const src_c = reinterpret_cast<const T*>(sg.src) + (size_t)b * sg.Lsrc * sg.Csrc + sg.c0 + cl;
+#pragma unroll
+      for (int i = 0; i < NPF; ++i) {
+        const int r = (tid >> 2) + 64 * i;
+        const int tm = g.base_time + r;
+        if (r < g.nrows && tm >= 0 && tm < g.row_bound) ra[i].load(src_c + (size_t)tm * sg.Csrc);
+      }
+    }
+    const int nvec = g.ntaps * CT * 4;
+#pragma unroll
+    for (int i = 0; i < NWV; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < nvec) {
+        const int row = idx >> 2, q = idx & 3;
+        const int tap = row / CT, col = row - tap * CT;
+        const long long e = sg.w_off + ((long long)((g.ch * g.ntaps + tap) * a.Cout + co0 + col)) * 32 + q * 8;
+        rwh[i] = *reinterpret_cast<const bf16x8*>(a.w_hi + e);
+        if constexpr (X3) rwl[i] = *reinterpret_cast<const bf16x8*>(a.w_lo + e);
+      }
+    }
+  };
+
+  auto store_stage = [&](const IterGeom& g, int buf) {
+    char* const act_hi = smem + buf * BUF_BYTES;
+    char* const act_lo = act_hi + ACT_BYTES;  // X3 only
+    char* const w_hi = act_hi + PLANES * ACT_BYTES;
+    char* const w_lo = w_hi + W_BYTES;  // X3 only
+    f32x8 sc, sh;
+    if (g.xform) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        sc[2 * j] = rss[j][0]; sh[2 * j] = rss[j][1]; sc[2 * j + 1] = rss[j][2]; sh[2 * j + 1] = rss[j][3];
+      }
+    }
+    if (!g.avg) {
+#pragma unroll
+      for (int i = 0; i < NPF; ++i) {
+        const int r = (tid >> 2) + 64 * i;
+        const int tm = g.base_time + r;
+        if (r < g.nrows) {
           f32x8 v = f32x8_zero();
-          if (tm >= 0 && tm < row_bound) {
-            if (avg) {
-              const T* p = src_c + (size_t)(2 * tm) * sg.Csrc;
-              f32x8 v0 = Elem<T>::load8(p);
-              f32x8 v1 = Elem<T>::load8(p + sg.Csrc);
-              if (xform) { v0 = affine_gelu(v0, sc, sh); v1 = affine_gelu(v1, sc, sh); }
-              v = (v0 + v1) * 0.5f;
-            } else {
-              v = Elem<T>::load8(src_c + (size_t)tm * sg.Csrc);
-              if (xform) v = affine_gelu(v, sc, sh);
-            }
+          if (tm >= 0 && tm < g.row_bound) {
+            v = ra[i].get();
+            if (g.xform) v = affine_gelu<X3>(v, sc, sh);
           }
           put_row<X3>(act_hi, act_lo, r * ROWB + oct * 16, v);
         }
       }
-      // ---------------- stage weights ----------------
-      {
-        const int nvec = ntaps * CT * 4;  // 16-byte pieces
-        for (int i = tid; i < nvec; i += 256) {
-          const int row = i >> 2, q = i & 3;
-          const int tap = row / CT, col = row - tap * CT;
-          const long long e = sg.w_off + ((long long)((ch * ntaps + tap) * a.Cout + co0 + col)) * 32 + q * 8;
-          *reinterpret_cast<bf16x8*>(w_hi + row * ROWB + q * 16) = *reinterpret_cast<const bf16x8*>(a.w_hi + e);
-          if constexpr (X3)
-            *reinterpret_cast<bf16x8*>(w_lo + row * ROWB + q * 16) = *reinterpret_cast<const bf16x8*>(a.w_lo + e);
+    } else {  // avg-pool segments (8 of 130 convs): staged synchronously, two source rows per LDS row
+      const SegDesc& sg = a.seg[g.s];
+      const T* const src_c = reinterpret_cast<const T*>(sg.src) + (size_t)b * sg.Lsrc * sg.Csrc + sg.c0 + g.ch * 32 + oct * 8;
+      for (int r = tid >> 2; r < g.nrows; r += 64) {
+        const int tm = g.base_time + r;
+        f32x8 v = f32x8_zero();
+        if (tm >= 0 && tm < g.row_bound) {
+          const T* p = src_c + (size_t)(2 * tm) * sg.Csrc;
+          f32x8 v0 = Elem<T>::load8(p);
+          f32x8 v1 = Elem<T>::load8(p + sg.Csrc);
+          if (g.xform) { v0 = affine_gelu<X3>(v0, sc, sh); v1 = affine_gelu<X3>(v1, sc, sh); }
+          v = (v0 + v1) * 0.5f;
         }
+        put_row<X3>(act_hi, act_lo, r * ROWB + oct * 16, v);
       }
-      __syncthreads();
-      // ---------------- MFMA ----------------
-      for (int k = 0; k < ntaps; ++k) {
-        const int toff = (ntaps == 3) ? (k - 1) * d : 0;
-        int arow[WM];
+    }
+    const int nvec = g.ntaps * CT * 4;
+#pragma unroll
+    for (int i = 0; i < NWV; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < nvec) {
+        const int row = idx >> 2, q = idx & 3;
+        *reinterpret_cast<bf16x8*>(w_hi + row * ROWB + q * 16) = rwh[i];
+        if constexpr (X3) *reinterpret_cast<bf16x8*>(w_lo + row * ROWB + q * 16) = rwl[i];
+      }
+    }
+  };
+
+  auto mfma_stage = [&](const IterGeom& g, int buf) {
+    const char* const act_hi = smem + buf * BUF_BYTES;
+    const char* const act_lo = act_hi + ACT_BYTES;
+    const char* const w_hi = act_hi + PLANES * ACT_BYTES;
+    const char* const w_lo = w_hi + W_BYTES;
+    for (int k = 0; k < g.ntaps; ++k) {
+      const int toff = (g.ntaps == 3) ? (k - 1) * g.d : 0;
+      int arow[WM];
+#pragma unroll
+      for (int mt = 0; mt < WM; ++mt) {
+        const int tl = wave * (WM * 32) + mt * 32 + l31;
+        arow[mt] = g.up ? (((tl + toff) >> 1) + 1) : (tl + toff + g.d);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int kb = ks * 32 + khalf;
+        bf16x8 ah[WM], al[WM], bh[WN], bl[WN];
 #pragma unroll
         for (int mt = 0; mt < WM; ++mt) {
-          const int tl = wave * (WM * 32) + mt * 32 + l31;
-          arow[mt] = up ? (((tl + toff) >> 1) + 1) : (tl + toff + d);
+          ah[mt] = *reinterpret_cast<const bf16x8*>(act_hi + arow[mt] * ROWB + kb);
+          if constexpr (X3) al[mt] = *reinterpret_cast<const bf16x8*>(act_lo + arow[mt] * ROWB + kb);
         }
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const int kb = ks * 32 + khalf;
-          bf16x8 ah[WM], al[WM], bh[WN], bl[WN];
+        for (int nt = 0; nt < WN; ++nt) {
+          const int wrow = k * CT + nt * 32 + l31;
+          bh[nt] = *reinterpret_cast<const bf16x8*>(w_hi + wrow * ROWB + kb);
+          if constexpr (X3) bl[nt] = *reinterpret_cast<const bf16x8*>(w_lo + wrow * ROWB + kb);
+        }
 #pragma unroll
-          for (int mt = 0; mt < WM; ++mt) {
-            ah[mt] = *reinterpret_cast<const bf16x8*>(act_hi + arow[mt] * ROWB + kb);
-            if constexpr (X3) al[mt] = *reinterpret_cast<const bf16x8*>(act_lo + arow[mt] * ROWB + kb);
-          }
+        for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
           for (int nt = 0; nt < WN; ++nt) {
-            const int wrow = k * CT + nt * 32 + l31;
-            bh[nt] = *reinterpret_cast<const bf16x8*>(w_hi + wrow * ROWB + kb);
-            if constexpr (X3) bl[nt] = *reinterpret_cast<const bf16x8*>(w_lo + wrow * ROWB + kb);
-          }
-#pragma unroll
-          for (int mt = 0; mt < WM; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < WN; ++nt) {
-              if constexpr (X3) {
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
-              }
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+            if constexpr (X3) {
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
             }
-        }
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+          }
       }
+    }
+  };
+
+  // ------------------------------ pipelined K loop ------------------------------
+  {
+    int s = 0, ch = 0;
+    IterGeom cur = geom(0, 0);
+    issue_loads(cur);
+    for (int it = 0; it < niter; ++it) {
+      const int buf = it & 1;
+      store_stage(cur, buf);  // consumes the registers loaded one iteration ago
+      IterGeom nxt = cur;
+      const bool more = it + 1 < niter;
+      if (more) {
+        if (++ch == (a.seg[s].C >> 5)) { ch = 0; ++s; }
+        nxt = geom(s, ch);
+        issue_loads(nxt);  // in flight across the barrier and the MFMAs below
+      }
+      __syncthreads();
+      mfma_stage(cur, buf);
+      cur = nxt;
     }
   }
 
@@ -190,16 +302,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 
   constexpr int OPR = CT / 8;     // 8-channel octets per row
   constexpr int RPP = 256 / OPR;  // rows per pass
-  const int oct = tid % OPR;
+  const int eoct = tid % OPR;
   const int r0 = tid / OPR;
-  const int cg = co0 + oct * 8;
+  const int cg = co0 + eoct * 8;
   const f32x8 bias8 = Elem<float>::load8(a.bias + cg);
   f32x8 s1 = f32x8_zero(), s2 = f32x8_zero();
   const T* const skip_b = a.skip ? reinterpret_cast<const T*>(a.skip) + (size_t)b * a.skip_L * a.skip_C + cg : nullptr;
   for (int r = r0; r < TT; r += RPP) {
     const int tm = t0 + r;
     if (tm >= a.Lout) break;
-    const float* o = ost + r * OS + oct * 8;
+    const float* o = ost + r * OS + eoct * 8;
     f32x8 v = Elem<float>::load8(o) + bias8;
     if (skip_b) {
       if (a.skip_resize == RESIZE_NONE) {
@@ -224,8 +336,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     float* const red = reinterpret_cast<float*>(smem);  // [RPP][CT][2]
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      red[(r0 * CT + oct * 8 + j) * 2 + 0] = s1[j];
-      red[(r0 * CT + oct * 8 + j) * 2 + 1] = s2[j];
+      red[(r0 * CT + eoct * 8 + j) * 2 + 0] = s1[j];
+      red[(r0 * CT + eoct * 8 + j) * 2 + 1] = s2[j];
     }
     __syncthreads();
     if (tid < CT) {
@@ -241,47 +353,57 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   }
 }
 
-template <bool X3, int WN>
+template <bool X3, int WN, int HALO>
 constexpr int lds_bytes() {
   constexpr int CT = WN * 32;
-  constexpr int stage = (X3 ? 2 : 1) * (ACT_BYTES + 3 * CT * ROWB);
+  constexpr int stage = 2 * (X3 ? 2 : 1) * (act_bytes<HALO>() + 3 * CT * ROWB);
   constexpr int ost = TT * (CT + 4) * 4;
   return stage > ost ? stage : ost;
 }
 
-template <typename T, bool X3, int WN>
+template <typename T, bool X3, int WN, int HALO>
 int launch_t(const ConvArgs& a, int B, hipStream_t st) {
-  constexpr int LDS = lds_bytes<X3, WN>();
+  constexpr int LDS = lds_bytes<X3, WN, HALO>();
+  static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool attr_done = false;
   if (!attr_done) {
-    VQVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<T, X3, WN>),
+    VQVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<T, X3, WN, HALO>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_done = true;
   }
   dim3 grid((a.Lout + TT - 1) / TT, a.Cout / (WN * 32), B);
-  hipLaunchKernelGGL((conv_mfma_kernel<T, X3, WN>), grid, dim3(256), LDS, st, a);
+  hipLaunchKernelGGL((conv_mfma_kernel<T, X3, WN, HALO>), grid, dim3(256), LDS, st, a);
   VQVS_HIP(hipGetLastError());
   return 0;
+}
+
+template <typename T, bool X3>
+int launch_p(const ConvArgs& a, int B, hipStream_t st, bool wide, bool big_halo) {
+  if (wide) return big_halo ? launch_t<T, X3, 2, 64>(a, B, st) : launch_t<T, X3, 2, 4>(a, B, st);
+  return big_halo ? launch_t<T, X3, 1, 64>(a, B, st) : launch_t<T, X3, 1, 4>(a, B, st);
 }
 
 }  // namespace
 
 int conv_lds_bytes(int precision, int wn) {
-  if (precision == 0) return wn == 2 ? lds_bytes<true, 2>() : lds_bytes<true, 1>();
-  return wn == 2 ? lds_bytes<false, 2>() : lds_bytes<false, 1>();
+  if (precision == 0) return wn == 2 ? lds_bytes<true, 2, 4>() : lds_bytes<true, 1, 4>();
+  return wn == 2 ? lds_bytes<false, 2, 4>() : lds_bytes<false, 1, 4>();
 }
 
 int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st) {
   if (a.Cout % 32 != 0 || a.nseg < 1 || a.nseg > 3) VQVS_FAIL(-1, "conv: unsupported shape Cout=%d nseg=%d", a.Cout, a.nseg);
+  int dmax = 0;
   for (int s = 0; s < a.nseg; ++s) {
     const SegDesc& g = a.seg[s];
     if (g.C % 32 != 0 || (g.ntaps != 1 && g.ntaps != 3) || g.dil > 32 || g.dil < 1)
       VQVS_FAIL(-1, "conv: unsupported segment C=%d taps=%d dil=%d", g.C, g.ntaps, g.dil);
     if (g.resize == RESIZE_UP2 && g.ntaps == 3 && g.dil != 1) VQVS_FAIL(-1, "conv: upsample needs dilation 1");
+    if (g.ntaps == 3 && g.dil > dmax) dmax = g.dil;
   }
   const bool wide = (a.Cout % 64) == 0;
-  if (precision == 0) return wide ? launch_t<float, true, 2>(a, B, st) : launch_t<float, true, 1>(a, B, st);
-  return wide ? launch_t<bf16_t, false, 2>(a, B, st) : launch_t<bf16_t, false, 1>(a, B, st);
+  const bool big_halo = dmax > 2;
+  if (precision == 0) return launch_p<float, true>(a, B, st, wide, big_halo);
+  return launch_p<bf16_t, false>(a, B, st, wide, big_halo);
 }
 
 }  // namespace vqvs

@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void in_conv_kernel(const InConvArgs a) {
 // ------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void out_conv_kernel(const OutConvArgs a) {
+  constexpr bool EXACT = sizeof(T) == 4;
   __shared__ float y[3][STAT_TILE + 2];
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
@@ -110,11 +111,11 @@ __global__ __launch_bounds__(256) void out_conv_kernel(const OutConvArgs a) {
     if (t >= 0 && t < a.L) {
       const f32x8 v = Elem<T>::load8(xb + (size_t)t * a.C);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float g = gelu_f(fmaf(v[j], sc[j], sh[j]));
-        p0 = fmaf(w0[j], g, p0);
-        p1 = fmaf(w1[j], g, p1);
-        p2 = fmaf(w2[j], g, p2);
+      for (int j = 0; j < 8; j += 2) {
+        const f32x2 g = gelu2<EXACT>(fma2(f32x2{v[j], v[j + 1]}, f32x2{sc[j], sc[j + 1]}, f32x2{sh[j], sh[j + 1]}));
+        p0 = fmaf(w0[j + 1], g[1], fmaf(w0[j], g[0], p0));
+        p1 = fmaf(w1[j + 1], g[1], fmaf(w1[j], g[0], p1));
+        p2 = fmaf(w2[j + 1], g[1], fmaf(w2[j], g[0], p2));
       }
     }
     for (int m = 1; m < opr; m <<= 1) {

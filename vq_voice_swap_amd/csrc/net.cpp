@@ -210,7 +210,7 @@ class Builder {
     const int lshift = srcs[0].lshift;
     Builder* self = this;
     std::vector<TensorH> S = srcs;
-    m_->meta.push_back({"gn_prepare", 0, 0, 0});
+    m_->meta.push_back({"gn_prepare", gn_name + " C=" + std::to_string(Ctot) + " L>>" + std::to_string(lshift), 0, 0, 0});
     m_->ops.push_back([=](const RunCtx& c) -> int {
       GnArgs a{};
       const int L = shiftL(c.Lbase, lshift);
@@ -261,7 +261,10 @@ class Builder {
     if (out.f32) conv_f32 += 4.0 * Cout * lscale(out.lshift);
     else conv_elems += Cout * lscale(out.lshift);
     const double conv_flops = 2.0 * Cout * ktot * lscale(out.lshift);
-    m_->meta.push_back({"conv", conv_elems, conv_f32, conv_flops});
+    std::string desc;
+    for (auto& s : segs) desc += (desc.empty() ? "" : "+") + std::to_string(s.C) + "x" + std::to_string(s.ntaps) + (s.resize == RESIZE_AVG2 ? "v" : s.resize == RESIZE_UP2 ? "^" : "") + (s.ntaps == 3 && s.dil > 1 ? "d" + std::to_string(s.dil) : "");
+    desc += "->" + std::to_string(Cout) + " L>>" + std::to_string(out.lshift) + (skip ? " +id" : "");
+    m_->meta.push_back({"conv", desc, conv_elems, conv_f32, conv_flops});
     m_->ops.push_back([=](const RunCtx& c) -> int {
       ConvArgs a{};
       a.nseg = (int)S.size();
@@ -502,7 +505,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
     const int E = c.rb_emb_channels;
     TensorH x = b.new_tensor(c.rb_cin, 0, false, true);
     const int Cin = c.rb_cin;
-    m->meta.push_back({"nct_to_ntc", 0, 0, 0});
+    m->meta.push_back({"nct_to_ntc", "", 0, 0, 0});
     m->ops.push_back([=](const RunCtx& r) -> int {
       return launch_nct_to_ntc(r.x, bp->act(x.off), bp->statp(x.stats_off), r.B, Cin, r.Lbase, ntiles_of(r.Lbase), prec, r.st);
     });
@@ -513,7 +516,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
       const size_t w_off = b.blob_f32("cond_layers.1.weight");
       const size_t bias_off = b.blob_f32("cond_layers.1.bias");
       const int R = 2 * c.rb_cout;
-      m->meta.push_back({"film", 0, 0, 0});
+      m->meta.push_back({"film", "", 0, 0, 0});
       m->ops.push_back([=](const RunCtx& r) -> int {
         if (!r.emb) VQVS_FAIL(VQVS_ERR_ARG, "resblock handle was built with an embedding; d_emb is NULL");
         if (int e = launch_gelu_rows(r.emb, bp->miscp(gemb), r.B * E, r.st)) return e;
@@ -524,7 +527,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
     }
     TensorH y = b.resblock("", s, {x}, E != 0, 0, 2 * c.rb_cout, film_misc);
     const int Cout = c.rb_cout;
-    m->meta.push_back({"ntc_to_nct", 0, 0, 0});
+    m->meta.push_back({"ntc_to_nct", "", 0, 0, 0});
     m->ops.push_back([=](const RunCtx& r) -> int {
       return launch_ntc_to_nct(bp->act(y.off), r.out, r.B, Cout, shiftL(r.Lbase, y.lshift), prec, r.st);
     });
@@ -544,7 +547,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
     const size_t emb_off = b.alloc_misc((size_t)c.max_batch * E);
     const size_t gemb_off = b.alloc_misc((size_t)c.max_batch * E);
     const int NL = c.num_labels;
-    m->meta.push_back({"time_embed", 0, 0, 0});
+    m->meta.push_back({"time_embed", "", 0, 0, 0});
     m->ops.push_back([=](const RunCtx& r) -> int {
       TimeEmbedArgs a{};
       a.ts = r.ts;
@@ -580,7 +583,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
     const size_t wall_off = b.blob.add(Wall.data(), Wall.size() * 4);
     const size_t ball_off = b.blob.add(ball.data(), ball.size() * 4);
     const size_t film_off = b.alloc_misc((size_t)c.max_batch * R);
-    m->meta.push_back({"film", 0, 0, 0});
+    m->meta.push_back({"film", "", 0, 0, 0});
     m->ops.push_back([=](const RunCtx& r) -> int {
       FilmArgs f{bp->miscp(gemb_off), reinterpret_cast<const float*>(bp->wp(wall_off)), reinterpret_cast<const float*>(bp->wp(ball_off)),
                  bp->miscp(film_off), E, R};
@@ -592,7 +595,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
     if (has_cond) {
       TensorH ct = b.new_tensor(c.cond_channels, 8, false, false);
       const int CC = c.cond_channels;
-      m->meta.push_back({"nct_to_ntc", 0, 0, 0});
+      m->meta.push_back({"nct_to_ntc", "", 0, 0, 0});
       m->ops.push_back([=](const RunCtx& r) -> int {
         return launch_nct_to_ntc(r.cond, bp->act(ct.off), nullptr, r.B, CC, r.Lbase >> 8, 0, prec, r.st);
       });
@@ -609,7 +612,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
     {
       const size_t w = b.blob_f32("in_conv.weight"), bi = b.blob_f32("in_conv.bias");
       const TensorH cp = condp;
-      m->meta.push_back({"in_conv", base + (has_cond ? base / 256.0 : 0.0), 4.0, 0});
+      m->meta.push_back({"in_conv", "1->" + std::to_string(base), base + (has_cond ? base / 256.0 : 0.0), 4.0, 0});
       m->ops.push_back([=](const RunCtx& r) -> int {
         InConvArgs a{};
         a.x = r.x;
@@ -669,7 +672,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
         for (int ci = 0; ci < base; ++ci) wt[k * base + ci] = W[ci * 3 + k];
       const size_t w = b.blob.add(wt.data(), wt.size() * 4);
       const float bias = b.P("out.1.bias")[0];
-      m->meta.push_back({"out_conv", (double)base, 4.0, 0});
+      m->meta.push_back({"out_conv", std::to_string(base) + "->1", (double)base, 4.0, 0});
       m->ops.push_back([=](const RunCtx& r) -> int {
         OutConvArgs a{};
         a.in = bp->act(h.off);
@@ -689,7 +692,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
       const float* bb = b.P("out.1.bias");
       b.add_conv({g}, pk, std::vector<float>(bb, bb + c.out_channels), c.out_channels, o, nullptr, 0);
       const int OC = c.out_channels;
-      m->meta.push_back({"ntc_to_nct", 0, 0, 0});
+      m->meta.push_back({"ntc_to_nct", "", 0, 0, 0});
       m->ops.push_back([=](const RunCtx& r) -> int { return launch_ntc_to_nct(bp->act(o.off), r.out, r.B, OC, r.Lbase, 0, r.st); });
     }
   } else {  // encoder (unet.py:229-241)
@@ -698,7 +701,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
     TensorH h = b.new_tensor(base, 0, false, true);
     {
       const size_t w = b.blob_f32("in_conv.weight"), bi = b.blob_f32("in_conv.bias");
-      m->meta.push_back({"in_conv", (double)base, 4.0, 0});
+      m->meta.push_back({"in_conv", "1->" + std::to_string(base), (double)base, 4.0, 0});
       m->ops.push_back([=](const RunCtx& r) -> int {
         InConvArgs a{};
         a.x = r.x;
@@ -731,7 +734,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
     const float* bb = b.P("out.1.bias");
     b.add_conv({g}, pk, std::vector<float>(bb, bb + c.out_channels), c.out_channels, o, nullptr, 0);
     const int OC = c.out_channels;
-    m->meta.push_back({"ntc_to_nct", 0, 0, 0});
+    m->meta.push_back({"ntc_to_nct", "", 0, 0, 0});
     m->ops.push_back([=](const RunCtx& r) -> int { return launch_ntc_to_nct(bp->act(o.off), r.out, r.B, OC, r.Lbase >> 8, 0, r.st); });
   }
 

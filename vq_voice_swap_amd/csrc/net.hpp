@@ -68,6 +68,7 @@ struct vqvs_model {
   std::vector<std::function<int(const vqvs::RunCtx&)>> ops;
   struct OpMeta {
     std::string kind;      // "conv", "gn_prepare", "in_conv", ...
+    std::string desc;      // human-readable shape (profiling tables)
     double elems_T = 0;    // algorithmic activation elements (storage type) per clip per unit of base length
     double bytes_f32 = 0;  // float32 boundary bytes per clip per unit of base length
     double flops = 0;      // per clip per unit of base length
