@@ -82,7 +82,7 @@ struct IterGeom {
   bool up, avg, xform;
 };
 
-template <typename T, bool X3, int WN, int HALO>
+template <typename T, bool X3, int WN, int HALO, bool SKIPV>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   constexpr int WM = 2;
   constexpr int CT = WN * 32;
@@ -263,6 +263,19 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     }
   };
 
+  // epilogue geometry (needed early: the identity-skip rows are prefetched before the last MFMA phase)
+  constexpr int OS = CT + 4;
+  constexpr int OPR = CT / 8;     // 8-channel octets per row
+  constexpr int RPP = 256 / OPR;  // rows per pass
+  constexpr int NEP = TT / RPP;   // passes
+  constexpr bool SKIP_PF = SKIPV && !X3;  // identity-skip variant; (fp32 mode: register budget)
+  const int eoct = tid % OPR;
+  const int r0 = tid / OPR;
+  const int cg = co0 + eoct * 8;
+  const T* const skip_b = a.skip ? reinterpret_cast<const T*>(a.skip) + (size_t)b * a.skip_L * a.skip_C + cg : nullptr;
+  const bool skip_pf = SKIP_PF && skip_b != nullptr && a.skip_resize != RESIZE_AVG2;
+  Raw8<T> rsk[SKIP_PF ? NEP : 1];
+
   // ------------------------------ pipelined K loop ------------------------------
   {
     int s = 0, ch = 0;
@@ -277,6 +290,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         if (++ch == (a.seg[s].C >> 5)) { ch = 0; ++s; }
         nxt = geom(s, ch);
         issue_loads(nxt);  // in flight across the barrier and the MFMAs below
+      } else if (skip_pf) {
+#pragma unroll
+        for (int i = 0; i < (SKIP_PF ? NEP : 1); ++i) {
+          const int tm = t0 + r0 + RPP * i;
+          if (tm < a.Lout) rsk[i].load(skip_b + (size_t)(a.skip_resize == RESIZE_UP2 ? (tm >> 1) : tm) * a.skip_C);
+        }
       }
       __syncthreads();
       mfma_stage(cur, buf);
@@ -286,7 +305,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 
   // ------------------------------ epilogue ------------------------------
   // accumulators -> LDS tile [256][CT+4] f32 -> whole-row reads: bias, skip, statistics, store.
-  constexpr int OS = CT + 4;
   float* const ost = reinterpret_cast<float*>(smem);
   __syncthreads();
 #pragma unroll
@@ -300,36 +318,32 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
       }
   __syncthreads();
 
-  constexpr int OPR = CT / 8;     // 8-channel octets per row
-  constexpr int RPP = 256 / OPR;  // rows per pass
-  const int eoct = tid % OPR;
-  const int r0 = tid / OPR;
-  const int cg = co0 + eoct * 8;
   const f32x8 bias8 = Elem<float>::load8(a.bias + cg);
   f32x8 s1 = f32x8_zero(), s2 = f32x8_zero();
-  const T* const skip_b = a.skip ? reinterpret_cast<const T*>(a.skip) + (size_t)b * a.skip_L * a.skip_C + cg : nullptr;
-  for (int r = r0; r < TT; r += RPP) {
+#pragma unroll
+  for (int i = 0; i < NEP; ++i) {
+    const int r = r0 + RPP * i;
     const int tm = t0 + r;
-    if (tm >= a.Lout) break;
-    const float* o = ost + r * OS + eoct * 8;
-    f32x8 v = Elem<float>::load8(o) + bias8;
-    if (skip_b) {
-      if (a.skip_resize == RESIZE_NONE) {
-        v += Elem<T>::load8(skip_b + (size_t)tm * a.skip_C);
-      } else if (a.skip_resize == RESIZE_AVG2) {
-        const T* p = skip_b + (size_t)(2 * tm) * a.skip_C;
-        v += (Elem<T>::load8(p) + Elem<T>::load8(p + a.skip_C)) * 0.5f;
-      } else {
-        v += Elem<T>::load8(skip_b + (size_t)(tm >> 1) * a.skip_C);
+    if (tm < a.Lout) {
+      f32x8 v = Elem<float>::load8(ost + r * OS + eoct * 8) + bias8;
+      if (skip_pf) {
+        v += rsk[SKIP_PF ? i : 0].get();
+      } else if (skip_b) {
+        if (a.skip_resize == RESIZE_AVG2) {  // avg-pooled identity skip (down-sampling blocks)
+          const T* p = skip_b + (size_t)(2 * tm) * a.skip_C;
+          v += (Elem<T>::load8(p) + Elem<T>::load8(p + a.skip_C)) * 0.5f;
+        } else {
+          v += Elem<T>::load8(skip_b + (size_t)(a.skip_resize == RESIZE_UP2 ? (tm >> 1) : tm) * a.skip_C);
+        }
       }
+      s1 += v;
+      s2 += v * v;
+      const size_t oidx = ((size_t)b * a.Lout + tm) * a.Cout + cg;
+      if (a.out_f32)
+        Elem<float>::store8(reinterpret_cast<float*>(a.out) + oidx, v);
+      else
+        Elem<T>::store8(reinterpret_cast<T*>(a.out) + oidx, v);
     }
-    s1 += v;
-    s2 += v * v;
-    const size_t oidx = ((size_t)b * a.Lout + tm) * a.Cout + cg;
-    if (a.out_f32)
-      Elem<float>::store8(reinterpret_cast<float*>(a.out) + oidx, v);
-    else
-      Elem<T>::store8(reinterpret_cast<T*>(a.out) + oidx, v);
   }
   if (a.stats) {
     __syncthreads();
@@ -361,26 +375,30 @@ constexpr int lds_bytes() {
   return stage > ost ? stage : ost;
 }
 
-template <typename T, bool X3, int WN, int HALO>
+template <typename T, bool X3, int WN, int HALO, bool SKIPV>
 int launch_t(const ConvArgs& a, int B, hipStream_t st) {
   constexpr int LDS = lds_bytes<X3, WN, HALO>();
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool attr_done = false;
   if (!attr_done) {
-    VQVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<T, X3, WN, HALO>),
+    VQVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<T, X3, WN, HALO, SKIPV>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_done = true;
   }
   dim3 grid((a.Lout + TT - 1) / TT, a.Cout / (WN * 32), B);
-  hipLaunchKernelGGL((conv_mfma_kernel<T, X3, WN, HALO>), grid, dim3(256), LDS, st, a);
+  hipLaunchKernelGGL((conv_mfma_kernel<T, X3, WN, HALO, SKIPV>), grid, dim3(256), LDS, st, a);
   VQVS_HIP(hipGetLastError());
   return 0;
 }
 
 template <typename T, bool X3>
 int launch_p(const ConvArgs& a, int B, hipStream_t st, bool wide, bool big_halo) {
-  if (wide) return big_halo ? launch_t<T, X3, 2, 64>(a, B, st) : launch_t<T, X3, 2, 4>(a, B, st);
-  return big_halo ? launch_t<T, X3, 1, 64>(a, B, st) : launch_t<T, X3, 1, 4>(a, B, st);
+  if (a.skip != nullptr && !X3) {
+    if (wide) return big_halo ? launch_t<T, X3, 2, 64, true>(a, B, st) : launch_t<T, X3, 2, 4, true>(a, B, st);
+    return big_halo ? launch_t<T, X3, 1, 64, true>(a, B, st) : launch_t<T, X3, 1, 4, true>(a, B, st);
+  }
+  if (wide) return big_halo ? launch_t<T, X3, 2, 64, false>(a, B, st) : launch_t<T, X3, 2, 4, false>(a, B, st);
+  return big_halo ? launch_t<T, X3, 1, 64, false>(a, B, st) : launch_t<T, X3, 1, 4, false>(a, B, st);
 }
 
 }  // namespace

@@ -129,6 +129,14 @@ struct FilmArgs {  // all blocks' cond_layers Linear at once: film[b][r] = bias[
 };
 int launch_film(const FilmArgs& a, int B, hipStream_t st);
 
+struct XformArgs {  // g = gelu(x*scale + shift) [+ avg_pool1d(.,2)], written once for convolutions whose
+  const void* in;    // output-channel tiling would otherwise repeat the prologue >= 4 times (Cout >= 256)
+  const float2* ss;  // [B][ss_stride], this tensor's channels start at ss_c0
+  void* out;         // [B][Lout][C] of T
+  int C, Lin, Lout, avg, ss_stride, ss_c0;
+};
+int launch_xform(const XformArgs& a, int B, int precision, hipStream_t st);
+
 // layout changes at the library boundary (reference tensors are NCT float32)
 int launch_nct_to_ntc(const float* in, void* out, float* stats, int B, int C, int L, int ntiles, int precision, hipStream_t st);
 int launch_ntc_to_nct(const void* in, float* out, int B, int C, int L, int in_precision, hipStream_t st);

@@ -139,46 +139,50 @@ __global__ __launch_bounds__(256) void out_conv_kernel(const OutConvArgs a) {
 // fixed order in fp64, so the result does not depend on scheduling.
 //   scale = rstd*gamma*(a+1),  shift = (beta - mean*rstd*gamma)*(a+1) + b
 // ------------------------------------------------------------------------------------
+constexpr int GN_SPLIT = 8;  // workgroups per clip (each owns groups/GN_SPLIT whole groups)
+
 __global__ __launch_bounds__(256) void gn_prepare_kernel(const GnArgs a) {
   __shared__ double part[256 * 2];
-  __shared__ double chs[1024], chq[1024];
+  __shared__ double chs[256], chq[256];
   __shared__ double gmean[32], grstd[32];
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
-  int cbase = 0;
-  for (int s = 0; s < a.nsrc; ++s) {
-    const GnSrc g = a.src[s];
-    const float* p = g.partials + (size_t)b * g.ntiles * g.C * 2;
-    for (int c0 = 0; c0 < g.C; c0 += 256) {
-      const int cw = min(256, g.C - c0);         // channels handled this round
-      const int nsl = 256 / cw;                  // tile slices per channel
-      const int c = tid % cw, sl = tid / cw;
-      double s1 = 0.0, s2 = 0.0;
-      if (sl < nsl) {
-        for (int t = sl; t < g.ntiles; t += nsl) {
-          const float2 q = *reinterpret_cast<const float2*>(p + ((size_t)t * g.C + c0 + c) * 2);
-          s1 += (double)q.x;
-          s2 += (double)q.y;
-        }
-        part[tid * 2] = s1;
-        part[tid * 2 + 1] = s2;
+  const int gs = a.Ctot / a.groups;                 // channels per group
+  const int ng = a.groups / gridDim.y;              // groups owned by this workgroup
+  const int c_lo = blockIdx.y * ng * gs;            // first channel owned
+  const int cw_tot = ng * gs;                       // channels owned
+  const int C0 = a.src[0].C;
+  for (int c0 = 0; c0 < cw_tot; c0 += 256) {
+    const int cw = min(256, cw_tot - c0);
+    const int nsl = 256 / cw;  // tile slices per channel
+    const int c = c_lo + c0 + tid % cw, sl = tid / cw;
+    double s1 = 0.0, s2 = 0.0;
+    if (sl < nsl) {
+      const bool second = c >= C0;
+      const GnSrc g = second ? a.src[1] : a.src[0];
+      const int cl = second ? c - C0 : c;
+      const float* p = g.partials + (size_t)b * g.ntiles * g.C * 2;
+      for (int t = sl; t < g.ntiles; t += nsl) {
+        const float2 q = *reinterpret_cast<const float2*>(p + ((size_t)t * g.C + cl) * 2);
+        s1 += (double)q.x;
+        s2 += (double)q.y;
       }
-      __syncthreads();
-      if (tid < cw) {
-        double t1 = 0.0, t2 = 0.0;
-        for (int k = 0; k < nsl; ++k) {
-          t1 += part[(k * cw + tid) * 2];
-          t2 += part[(k * cw + tid) * 2 + 1];
-        }
-        chs[cbase + c0 + tid] = t1;
-        chq[cbase + c0 + tid] = t2;
-      }
-      __syncthreads();
+      part[tid * 2] = s1;
+      part[tid * 2 + 1] = s2;
     }
-    cbase += g.C;
+    __syncthreads();
+    if (tid < cw) {
+      double t1 = 0.0, t2 = 0.0;
+      for (int k = 0; k < nsl; ++k) {  // fixed order: deterministic
+        t1 += part[(k * cw + tid) * 2];
+        t2 += part[(k * cw + tid) * 2 + 1];
+      }
+      chs[c0 + tid] = t1;
+      chq[c0 + tid] = t2;
+    }
+    __syncthreads();
   }
-  const int gs = a.Ctot / a.groups;
-  if (tid < a.groups) {
+  if (tid < ng) {
     double t1 = 0.0, t2 = 0.0;
     for (int j = 0; j < gs; ++j) {
       t1 += chs[tid * gs + j];
@@ -191,8 +195,9 @@ __global__ __launch_bounds__(256) void gn_prepare_kernel(const GnArgs a) {
     grstd[tid] = 1.0 / sqrt(var + 1e-5);
   }
   __syncthreads();
-  for (int c = tid; c < a.Ctot; c += 256) {
-    const int g = c / gs;
+  for (int i = tid; i < cw_tot; i += 256) {
+    const int c = c_lo + i;
+    const int g = i / gs;
     double scale = grstd[g] * (double)a.gamma[c];
     double shift = (double)a.beta[c] - gmean[g] * scale;
     if (a.film) {
@@ -281,6 +286,46 @@ __global__ __launch_bounds__(256) void film_kernel(const FilmArgs a, int B) {
 }
 
 // ------------------------------------------------------------------------------------
+// Stand-alone prologue for the deep levels: g = gelu(x*scale+shift) (optionally avg-pooled by 2).
+// One thread = 8 channels of one output row.
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void xform_kernel(const XformArgs a) {
+  constexpr bool EXACT = sizeof(T) == 4;
+  const int b = blockIdx.y;
+  const int opr = a.C >> 3;
+  const long long item = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (item >= (long long)a.Lout * opr) return;
+  const int t = (int)(item / opr), c = (int)(item % opr) * 8;
+  f32x8 sc, sh;
+  const float2* p = a.ss + (size_t)b * a.ss_stride + a.ss_c0 + c;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float2 q = p[j];
+    sc[j] = q.x;
+    sh[j] = q.y;
+  }
+  const T* in = reinterpret_cast<const T*>(a.in) + (size_t)b * a.Lin * a.C + c;
+  auto tr = [&](f32x8 v) {
+    f32x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      const f32x2 g = gelu2<EXACT>(fma2(f32x2{v[j], v[j + 1]}, f32x2{sc[j], sc[j + 1]}, f32x2{sh[j], sh[j + 1]}));
+      r[j] = g[0];
+      r[j + 1] = g[1];
+    }
+    return r;
+  };
+  f32x8 v;
+  if (a.avg) {
+    v = (tr(Elem<T>::load8(in + (size_t)(2 * t) * a.C)) + tr(Elem<T>::load8(in + (size_t)(2 * t + 1) * a.C))) * 0.5f;
+  } else {
+    v = tr(Elem<T>::load8(in + (size_t)t * a.C));
+  }
+  Elem<T>::store8(reinterpret_cast<T*>(a.out) + ((size_t)b * a.Lout + t) * a.C + c, v);
+}
+
+// ------------------------------------------------------------------------------------
 // NCT float32 <-> NTC T, 32x32 tiles through LDS (used only at the library boundary:
 // conditioning input, encoder output, unit-test handles, debug taps).
 // ------------------------------------------------------------------------------------
@@ -362,7 +407,10 @@ int launch_out_conv(const OutConvArgs& a, int B, int precision, hipStream_t st) 
 
 int launch_gn_prepare(const GnArgs& a, int B, hipStream_t st) {
   if (a.Ctot > 1024 || a.groups > 32 || a.Ctot % a.groups) VQVS_FAIL(-1, "gn: unsupported Ctot=%d groups=%d", a.Ctot, a.groups);
-  hipLaunchKernelGGL(gn_prepare_kernel, dim3(B), dim3(256), 0, st, a);
+  int split = GN_SPLIT;
+  while (split > 1 && (a.groups % split || (a.groups / split) * (a.Ctot / a.groups) > 256)) split >>= 1;
+  if ((a.groups / split) * (a.Ctot / a.groups) > 256 && a.Ctot > 256) split = a.groups;  // one group per workgroup
+  hipLaunchKernelGGL(gn_prepare_kernel, dim3(B, split), dim3(256), 0, st, a);
   VQVS_HIP(hipGetLastError());
   return 0;
 }
@@ -390,6 +438,18 @@ int launch_film(const FilmArgs& a, int B, hipStream_t st) {
     case 1024: hipLaunchKernelGGL(film_kernel<16>, grid, blk, 0, st, a, B); break;
     default: VQVS_FAIL(-1, "film: unsupported E=%d", a.E);
   }
+  VQVS_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_xform(const XformArgs& a, int B, int precision, hipStream_t st) {
+  if (a.C % 8) VQVS_FAIL(-1, "xform: unsupported C=%d", a.C);
+  const long long items = (long long)a.Lout * (a.C / 8);
+  dim3 grid((unsigned)((items + 255) / 256), B);
+  if (precision == 0)
+    hipLaunchKernelGGL(xform_kernel<float>, grid, dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(xform_kernel<bf16_t>, grid, dim3(256), 0, st, a);
   VQVS_HIP(hipGetLastError());
   return 0;
 }
