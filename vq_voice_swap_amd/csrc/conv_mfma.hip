@@ -27,7 +27,6 @@ namespace {
 
 constexpr int TT = 256;   // time rows per workgroup (== STAT_TILE)
 constexpr int ROWB = 80;  // LDS bytes per 32-channel row (64 data + 16 pad)
-constexpr int NPF = 5;    // prefetched (row, octet) items per thread: covers 320 rows x 4 octets
 
 template <int HALO>
 constexpr int act_bytes() { return (TT + HALO) * ROWB; }
@@ -82,20 +81,23 @@ struct IterGeom {
   bool up, avg, xform;
 };
 
-template <typename T, bool X3, int WN, int HALO, bool SKIPV>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
+template <typename T, bool X3, int WN, int HALO, bool SKIPV, int WGN>
+__global__ __launch_bounds__(256 * WGN) void conv_mfma_kernel(const ConvArgs a) {
+  constexpr int NTH = 256 * WGN;  // 4 waves along time x WGN waves along output channels
+  constexpr int NPF = (320 * 4 + NTH - 1) / NTH;  // prefetched (row, octet) items per thread (covers 320 rows x 4 octets)
   constexpr int WM = 2;
-  constexpr int CT = WN * 32;
+  constexpr int CT = WGN * WN * 32;
   constexpr int ACT_BYTES = act_bytes<HALO>();
   constexpr int W_BYTES = 3 * CT * ROWB;
-  constexpr int NWV = (3 * CT * 4 + 255) / 256;  // 16-byte weight pieces per thread per chunk
+  constexpr int NWV = (3 * CT * 4 + NTH - 1) / NTH;  // 16-byte weight pieces per thread per chunk
   constexpr int PLANES = X3 ? 2 : 1;
   constexpr int BUF_BYTES = PLANES * (ACT_BYTES + W_BYTES);
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = (tid >> 6) & 3;   // position along time
+  const int wvn = tid >> 8;          // position along output channels (0 .. WGN-1)
   const int b = blockIdx.z;
   const int co0 = blockIdx.y * CT;
   const int t0 = blockIdx.x * TT;
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
       const T* const src_c = reinterpret_cast<const T*>(sg.src) + (size_t)b * sg.Lsrc * sg.Csrc + sg.c0 + cl;
 #pragma unroll
       for (int i = 0; i < NPF; ++i) {
-        const int r = (tid >> 2) + 64 * i;
+        const int r = (tid >> 2) + (NTH / 4) * i;
         const int tm = g.base_time + r;
         if (r < g.nrows && tm >= 0 && tm < g.row_bound) ra[i].load(src_c + (size_t)tm * sg.Csrc);
       }
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     const int nvec = g.ntaps * CT * 4;
 #pragma unroll
     for (int i = 0; i < NWV; ++i) {
-      const int idx = tid + 256 * i;
+      const int idx = tid + NTH * i;
       if (idx < nvec) {
         const int row = idx >> 2, q = idx & 3;
         const int tap = row / CT, col = row - tap * CT;
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     if (!g.avg) {
 #pragma unroll
       for (int i = 0; i < NPF; ++i) {
-        const int r = (tid >> 2) + 64 * i;
+        const int r = (tid >> 2) + (NTH / 4) * i;
         const int tm = g.base_time + r;
         if (r < g.nrows) {
           f32x8 v = f32x8_zero();
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     } else {  // avg-pool segments (8 of 130 convs): staged synchronously, two source rows per LDS row
       const SegDesc& sg = a.seg[g.s];
       const T* const src_c = reinterpret_cast<const T*>(sg.src) + (size_t)b * sg.Lsrc * sg.Csrc + sg.c0 + g.ch * 32 + oct * 8;
-      for (int r = tid >> 2; r < g.nrows; r += 64) {
+      for (int r = tid >> 2; r < g.nrows; r += NTH / 4) {
         const int tm = g.base_time + r;
         f32x8 v = f32x8_zero();
         if (tm >= 0 && tm < g.row_bound) {
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     const int nvec = g.ntaps * CT * 4;
 #pragma unroll
     for (int i = 0; i < NWV; ++i) {
-      const int idx = tid + 256 * i;
+      const int idx = tid + NTH * i;
       if (idx < nvec) {
         const int row = idx >> 2, q = idx & 3;
         *reinterpret_cast<bf16x8*>(w_hi + row * ROWB + q * 16) = rwh[i];
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         }
 #pragma unroll
         for (int nt = 0; nt < WN; ++nt) {
-          const int wrow = k * CT + nt * 32 + l31;
+          const int wrow = k * CT + (wvn * WN + nt) * 32 + l31;
           bh[nt] = *reinterpret_cast<const bf16x8*>(w_hi + wrow * ROWB + kb);
           if constexpr (X3) bl[nt] = *reinterpret_cast<const bf16x8*>(w_lo + wrow * ROWB + kb);
         }
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   // epilogue geometry (needed early: the identity-skip rows are prefetched before the last MFMA phase)
   constexpr int OS = CT + 4;
   constexpr int OPR = CT / 8;     // 8-channel octets per row
-  constexpr int RPP = 256 / OPR;  // rows per pass
+  constexpr int RPP = NTH / OPR;  // rows per pass
   constexpr int NEP = TT / RPP;   // passes
   constexpr bool SKIP_PF = SKIPV && !X3;  // identity-skip variant; (fp32 mode: register budget)
   const int eoct = tid % OPR;
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = wave * (WM * 32) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        ost[row * OS + nt * 32 + l31] = acc[mt][nt][r];
+        ost[row * OS + (wvn * WN + nt) * 32 + l31] = acc[mt][nt][r];
       }
   __syncthreads();
 
@@ -367,32 +369,39 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   }
 }
 
-template <bool X3, int WN, int HALO>
+template <bool X3, int WN, int HALO, int WGN = 1>
 constexpr int lds_bytes() {
-  constexpr int CT = WN * 32;
+  constexpr int CT = WGN * WN * 32;
   constexpr int stage = 2 * (X3 ? 2 : 1) * (act_bytes<HALO>() + 3 * CT * ROWB);
   constexpr int ost = TT * (CT + 4) * 4;
   return stage > ost ? stage : ost;
 }
 
-template <typename T, bool X3, int WN, int HALO, bool SKIPV>
+template <typename T, bool X3, int WN, int HALO, bool SKIPV, int WGN = 1>
 int launch_t(const ConvArgs& a, int B, hipStream_t st) {
-  constexpr int LDS = lds_bytes<X3, WN, HALO>();
+  constexpr int LDS = lds_bytes<X3, WN, HALO, WGN>();
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool attr_done = false;
   if (!attr_done) {
-    VQVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<T, X3, WN, HALO, SKIPV>),
+    VQVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<T, X3, WN, HALO, SKIPV, WGN>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_done = true;
   }
-  dim3 grid((a.Lout + TT - 1) / TT, a.Cout / (WN * 32), B);
-  hipLaunchKernelGGL((conv_mfma_kernel<T, X3, WN, HALO, SKIPV>), grid, dim3(256), LDS, st, a);
+  dim3 grid((a.Lout + TT - 1) / TT, a.Cout / (WGN * WN * 32), B);
+  hipLaunchKernelGGL((conv_mfma_kernel<T, X3, WN, HALO, SKIPV, WGN>), grid, dim3(256 * WGN), LDS, st, a);
   VQVS_HIP(hipGetLastError());
   return 0;
 }
 
 template <typename T, bool X3>
 int launch_p(const ConvArgs& a, int B, hipStream_t st, bool wide, bool big_halo) {
+  if constexpr (!X3) {
+    // 128-channel output tiles (8 waves): the prologue and the activation reads are shared by twice as many channels
+    if (a.Cout % 128 == 0) {
+      if (a.skip != nullptr) return big_halo ? launch_t<T, X3, 2, 64, true, 2>(a, B, st) : launch_t<T, X3, 2, 4, true, 2>(a, B, st);
+      return big_halo ? launch_t<T, X3, 2, 64, false, 2>(a, B, st) : launch_t<T, X3, 2, 4, false, 2>(a, B, st);
+    }
+  }
   if (a.skip != nullptr && !X3) {
     if (wide) return big_halo ? launch_t<T, X3, 2, 64, true>(a, B, st) : launch_t<T, X3, 2, 4, true>(a, B, st);
     return big_halo ? launch_t<T, X3, 1, 64, true>(a, B, st) : launch_t<T, X3, 1, 4, true>(a, B, st);
