@@ -18,7 +18,9 @@ import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+REFERENCE = "/root/reference"
+# the repo also ships an import shim called `vq_voice_swap`; the REFERENCE must win here
+sys.path = [REFERENCE] + [p for p in sys.path if os.path.abspath(p or ".") not in (ROOT, REFERENCE)] + [ROOT]
 
 from oracle import ref_cpu  # noqa: E402
 from vq_voice_swap_amd.det_init import det_init_  # noqa: E402
@@ -26,6 +28,10 @@ from vq_voice_swap_amd.det_init import det_init_  # noqa: E402
 from vq_voice_swap.diffusion_model import DiffusionModel  # noqa: E402  (reference)
 from vq_voice_swap.models.unet import ResBlock  # noqa: E402  (reference)
 from vq_voice_swap.vq_vae import VQVAE  # noqa: E402  (reference)
+
+import vq_voice_swap as _ref_pkg  # noqa: E402
+
+assert os.path.abspath(_ref_pkg.__file__).startswith(REFERENCE), f"not the reference: {_ref_pkg.__file__}"
 
 OUT = os.path.join(ROOT, "tests", "golden")
 os.makedirs(OUT, exist_ok=True)

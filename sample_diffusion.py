@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""
+Sample waveforms from a diffusion model on MI355X.  Counterpart of the reference's sample_diffusion.py
+(same flags; reference sample_diffusion.py:125-141), running on the gfx950 library: x_T ~ N(0,1), optional
+class labels (uniform or --target-class), `ddpm_sample`, one 16 kHz mono s16 WAV per clip.
+Differences: WAV files are written directly (no ffmpeg); `--schedule` accepts "lambda t: t" / "lambda t: t**P"
+without eval; `--seed`, `--precision` are new; classifier guidance needs the classifier model, which is not
+built yet and is rejected with a clear error.
+"""
+import argparse
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from vq_voice_swap_amd import DiffusionModel, randn_clips  # noqa: E402
+from vq_voice_swap_amd.audio import ChunkWriter, parse_time_schedule  # noqa: E402
+
+
+def arg_parser():
+    p = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    p.add_argument("--checkpoint-path", default="model_diffusion.pt", type=str)
+    p.add_argument("--sample-steps", default=100, type=int)
+    p.add_argument("--batch-size", default=1, type=int)
+    p.add_argument("--constrain", action="store_true")
+    p.add_argument("--sample-path", default="sample.wav", type=str)
+    p.add_argument("--num-samples", default=None, type=int)
+    p.add_argument("--grad-checkpoint", action="store_true")
+    p.add_argument("--classifier-path", default=None, type=str)
+    p.add_argument("--classifier-scale", default=1.0, type=float)
+    p.add_argument("--target-class", default=None, type=int)
+    p.add_argument("--schedule", default="lambda t: t", type=str)
+    p.add_argument("--encoding", default="linear", type=str)
+    p.add_argument("--seed", default=None, type=int)
+    p.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
+    return p
+
+
+def sample_labels(args, num_labels, n, device, gen):
+    if args.target_class is not None:
+        out = torch.tensor([args.target_class] * n)
+    else:
+        out = torch.randint(low=0, high=num_labels, size=(n,), generator=gen)
+    return out.to(dtype=torch.long, device=device)
+
+
+def sample_batch(args, model, device, n, seed, clip_offset, schedule, gen):
+    x_T = randn_clips(n, 64000, device, seed, clip_offset=clip_offset)
+    pred = model.predictor
+    if model.num_labels is not None:
+        labels = sample_labels(args, model.num_labels, n, device, gen)
+        pred = lambda xs, ts, _l=labels: model.predictor(xs, ts, labels=_l)  # noqa: E731
+    return model.diffusion.ddpm_sample(x_T, pred, args.sample_steps, progress=n == 1, constrain=args.constrain,
+                                       schedule=schedule, seed=seed, clip_offset=clip_offset)
+
+
+def write_clip(path, seq, encoding):
+    w = ChunkWriter(path, 16000, encoding=encoding)
+    w.write(seq.reshape(-1).cpu().numpy())
+    w.close()
+
+
+def main(argv=None):
+    args = arg_parser().parse_args(argv)
+    if args.classifier_path:
+        raise SystemExit("classifier-guided sampling needs the Classifier model (SURVEY.md 8f.1), which this build does not include yet")
+    schedule = parse_time_schedule(args.schedule)
+    model = DiffusionModel.load(args.checkpoint_path)
+    if not torch.cuda.is_available():
+        raise SystemExit("no ROCm device visible: the sampler has no CPU path")
+    device = torch.device("cuda")
+    model.to(device)
+    model.eval()
+    model.set_precision(args.precision)
+    seed = args.seed if args.seed is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
+    gen = torch.Generator().manual_seed(seed % (2 ** 63))
+    if args.num_samples is None:
+        write_clip(args.sample_path, sample_batch(args, model, device, 1, seed, 0, schedule, gen)[0], args.encoding)
+        return
+    os.mkdir(args.sample_path)
+    count = 0
+    for b in range(int(math.ceil(args.num_samples / args.batch_size))):
+        sample = sample_batch(args, model, device, args.batch_size, seed, b * args.batch_size, schedule, gen)
+        for seq in sample:
+            if count == args.num_samples:
+                break
+            write_clip(os.path.join(args.sample_path, f"sample_{count:06}.wav"), seq, args.encoding)
+            count += 1
+
+
+if __name__ == "__main__":
+    main()
