@@ -25,10 +25,10 @@ namespace vqvs {
 
 namespace {
 
-constexpr int TT = 256;   // time rows per workgroup (== STAT_TILE)
+constexpr int TT_MAX = 256;  // staged time rows per workgroup (WM = 2); WM = 1 workgroups stage 128
 constexpr int ROWB = 80;  // LDS bytes per 32-channel row (64 data + 16 pad)
 
-template <int HALO>
+template <int HALO, int TT>
 constexpr int act_bytes() { return (TT + HALO) * ROWB; }
 
 template <bool X3>
@@ -81,13 +81,13 @@ struct IterGeom {
   bool up, avg, xform;
 };
 
-template <typename T, bool X3, int WN, int HALO, bool SKIPV, int WGN>
+template <typename T, bool X3, int WN, int HALO, bool SKIPV, int WGN, int WM>
 __global__ __launch_bounds__(256 * WGN) void conv_mfma_kernel(const ConvArgs a) {
+  constexpr int TT = 4 * WM * 32;  // staged rows: 4 waves along time x WM MFMA tiles of 32 rows
   constexpr int NTH = 256 * WGN;  // 4 waves along time x WGN waves along output channels
-  constexpr int NPF = (320 * 4 + NTH - 1) / NTH;  // prefetched (row, octet) items per thread (covers 320 rows x 4 octets)
-  constexpr int WM = 2;
+  constexpr int NPF = (TT * 4) / NTH;  // prefetched (row, octet) items per thread: exactly the 256 staged rows x 4 octets
   constexpr int CT = WGN * WN * 32;
-  constexpr int ACT_BYTES = act_bytes<HALO>();
+  constexpr int ACT_BYTES = act_bytes<HALO, TT>();
   constexpr int W_BYTES = 3 * CT * ROWB;
   constexpr int NWV = (3 * CT * 4 + NTH - 1) / NTH;  // 16-byte weight pieces per thread per chunk
   constexpr int PLANES = X3 ? 2 : 1;
@@ -100,7 +100,10 @@ __global__ __launch_bounds__(256 * WGN) void conv_mfma_kernel(const ConvArgs a) 
   const int wvn = tid >> 8;          // position along output channels (0 .. WGN-1)
   const int b = blockIdx.z;
   const int co0 = blockIdx.y * CT;
-  const int t0 = blockIdx.x * TT;
+  // A tile produces tile_rows = 256 - 2*dmax output rows, so that rows + halo = 256 staged rows = a whole number
+  // of (row, octet) items per thread: no wave carries an extra, mostly empty, halo item to every barrier.
+  const int TTO = a.tile_rows;
+  const int t0 = blockIdx.x * TTO;
   const int oct = tid & 3;
   const int l31 = lane & 31;
   const int khalf = (lane >> 5) * 16;
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(256 * WGN) void conv_mfma_kernel(const ConvArgs a) 
     g.up = sg.resize == RESIZE_UP2;
     g.avg = sg.resize == RESIZE_AVG2;
     g.xform = sg.ss != nullptr;
-    g.nrows = g.up ? (TT / 2 + 2) : (TT + 2 * g.d);
+    g.nrows = g.up ? (TTO / 2 + 2) : (TTO + 2 * g.d);
     g.base_time = g.up ? ((t0 >> 1) - 1) : (t0 - g.d);
     g.row_bound = g.avg ? a.Lout : sg.Lsrc;
     return g;
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(256 * WGN) void conv_mfma_kernel(const ConvArgs a) 
 #pragma unroll
         for (int i = 0; i < (SKIP_PF ? NEP : 1); ++i) {
           const int tm = t0 + r0 + RPP * i;
-          if (tm < a.Lout) rsk[i].load(skip_b + (size_t)(a.skip_resize == RESIZE_UP2 ? (tm >> 1) : tm) * a.skip_C);
+          if (r0 + RPP * i < TTO && tm < a.Lout) rsk[i].load(skip_b + (size_t)(a.skip_resize == RESIZE_UP2 ? (tm >> 1) : tm) * a.skip_C);
         }
       }
       __syncthreads();
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(256 * WGN) void conv_mfma_kernel(const ConvArgs a) 
   for (int i = 0; i < NEP; ++i) {
     const int r = r0 + RPP * i;
     const int tm = t0 + r;
-    if (tm < a.Lout) {
+    if (r < TTO && tm < a.Lout) {
       f32x8 v = Elem<float>::load8(ost + r * OS + eoct * 8) + bias8;
       if (skip_pf) {
         v += rsk[SKIP_PF ? i : 0].get();
@@ -369,32 +372,33 @@ __global__ __launch_bounds__(256 * WGN) void conv_mfma_kernel(const ConvArgs a) 
   }
 }
 
-template <bool X3, int WN, int HALO, int WGN = 1>
+template <bool X3, int WN, int HALO, int WGN = 1, int WM = 2>
 constexpr int lds_bytes() {
   constexpr int CT = WGN * WN * 32;
-  constexpr int stage = 2 * (X3 ? 2 : 1) * (act_bytes<HALO>() + 3 * CT * ROWB);
+  constexpr int TT = 4 * WM * 32;
+  constexpr int stage = 2 * (X3 ? 2 : 1) * (act_bytes<HALO, TT>() + 3 * CT * ROWB);
   constexpr int ost = TT * (CT + 4) * 4;
   return stage > ost ? stage : ost;
 }
 
-template <typename T, bool X3, int WN, int HALO, bool SKIPV, int WGN = 1>
+template <typename T, bool X3, int WN, int HALO, bool SKIPV, int WGN = 1, int WM = 2>
 int launch_t(const ConvArgs& a, int B, hipStream_t st) {
-  constexpr int LDS = lds_bytes<X3, WN, HALO, WGN>();
+  constexpr int LDS = lds_bytes<X3, WN, HALO, WGN, WM>();
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool attr_done = false;
   if (!attr_done) {
-    VQVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<T, X3, WN, HALO, SKIPV, WGN>),
+    VQVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<T, X3, WN, HALO, SKIPV, WGN, WM>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_done = true;
   }
-  dim3 grid((a.Lout + TT - 1) / TT, a.Cout / (WGN * WN * 32), B);
-  hipLaunchKernelGGL((conv_mfma_kernel<T, X3, WN, HALO, SKIPV, WGN>), grid, dim3(256 * WGN), LDS, st, a);
+  dim3 grid((a.Lout + a.tile_rows - 1) / a.tile_rows, a.Cout / (WGN * WN * 32), B);
+  hipLaunchKernelGGL((conv_mfma_kernel<T, X3, WN, HALO, SKIPV, WGN, WM>), grid, dim3(256 * WGN), LDS, st, a);
   VQVS_HIP(hipGetLastError());
   return 0;
 }
 
 template <typename T, bool X3>
-int launch_p(const ConvArgs& a, int B, hipStream_t st, bool wide, bool big_halo) {
+int launch_p(const ConvArgs& a, int B, hipStream_t st, bool wide, bool big_halo, int dmax) {
   if constexpr (!X3) {
     // 128-channel output tiles (8 waves): the prologue and the activation reads are shared by twice as many channels
     if (a.Cout % 128 == 0) {
@@ -411,6 +415,10 @@ int launch_p(const ConvArgs& a, int B, hipStream_t st, bool wide, bool big_halo)
 }
 
 }  // namespace
+
+// (128-row tiles with three workgroups per CU were measured 10-25 % slower than 256-row tiles: the per-tile
+// fixed costs double while the SIMDs are already ~70 % busy.)
+int conv_tile_rows(int dmax, int /*Cout*/, int /*precision*/) { return TT_MAX - 2 * dmax; }
 
 int conv_lds_bytes(int precision, int wn) {
   if (precision == 0) return wn == 2 ? lds_bytes<true, 2, 4>() : lds_bytes<true, 1, 4>();
@@ -429,8 +437,9 @@ int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st) {
   }
   const bool wide = (a.Cout % 64) == 0;
   const bool big_halo = dmax > 2;
-  if (precision == 0) return launch_p<float, true>(a, B, st, wide, big_halo);
-  return launch_p<bf16_t, false>(a, B, st, wide, big_halo);
+  if (a.tile_rows != conv_tile_rows(dmax, a.Cout, precision)) VQVS_FAIL(-1, "conv: tile_rows %d does not match dilation %d", a.tile_rows, dmax);
+  if (precision == 0) return launch_p<float, true>(a, B, st, wide, big_halo, dmax);
+  return launch_p<bf16_t, false>(a, B, st, wide, big_halo, dmax);
 }
 
 }  // namespace vqvs

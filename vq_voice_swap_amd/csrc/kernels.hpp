@@ -57,12 +57,14 @@ struct ConvArgs {
   int skip_C, skip_L, skip_resize;
   void* out;       // [B][Lout][Cout] of T (or float if out_f32)
   int out_f32;
-  float* stats;  // [B][ntiles][Cout][2] or nullptr
-  int ntiles;
+  float* stats;   // [B][ntiles][Cout][2] or nullptr
+  int ntiles;     // ceil(Lout / tile_rows)
+  int tile_rows;  // output rows per workgroup = conv_tile_rows(max dilation of the 3-tap segments)
 };
 
 int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st);
 int conv_lds_bytes(int precision, int wn);
+int conv_tile_rows(int dmax, int Cout, int precision);
 
 // ----------------------------------------------------------------------------------
 // small kernels

@@ -136,7 +136,8 @@ struct PackedConv {
 
 double lscale(int lshift) { return lshift >= 0 ? 1.0 / (double)(1 << lshift) : (double)(1 << -lshift); }
 int shiftL(int L, int lshift) { return lshift >= 0 ? (L >> lshift) : (L << -lshift); }
-int ntiles_of(int L) { return (L + STAT_TILE - 1) / STAT_TILE; }
+int ntiles_of(int L, int rows = STAT_TILE) { return (L + rows - 1) / rows; }
+constexpr int MIN_TILE_ROWS = 124;  // the smallest statistics tile any producer uses (128-row tiles, dilation 2)
 
 class Builder {
  public:
@@ -172,10 +173,12 @@ class Builder {
     if (stats) {
       t.has_stats = true;
       t.stats_off = stats_floats;
-      stats_floats += (size_t)maxB_ * ntiles_of(shiftL(maxL_, lshift)) * C * 2;
+      stats_floats += (size_t)maxB_ * ntiles_of(shiftL(maxL_, lshift), MIN_TILE_ROWS) * C * 2;
+      tile_rows_[t.id] = STAT_TILE;
     }
     return t;
   }
+  int stat_rows(const TensorH& t) const { return tile_rows_.at(t.id); }
   void retain(const TensorH& t) { refs_[t.id]++; }
   void release(const TensorH& t) {
     if (--refs_[t.id] == 0 && !m_->cfg.debug_taps) arena_free(offs_[t.id], sizes_[t.id]);
@@ -210,12 +213,14 @@ class Builder {
     const int lshift = srcs[0].lshift;
     Builder* self = this;
     std::vector<TensorH> S = srcs;
+    std::vector<int> SR;
+    for (auto& t : srcs) SR.push_back(stat_rows(t));
     m_->meta.push_back({"gn_prepare", gn_name + " C=" + std::to_string(Ctot) + " L>>" + std::to_string(lshift), 0, 0, 0});
     m_->ops.push_back([=](const RunCtx& c) -> int {
       GnArgs a{};
       const int L = shiftL(c.Lbase, lshift);
       a.nsrc = (int)S.size();
-      for (int i = 0; i < a.nsrc; ++i) a.src[i] = GnSrc{self->statp(S[i].stats_off), ntiles_of(L), S[i].C};
+      for (int i = 0; i < a.nsrc; ++i) a.src[i] = GnSrc{self->statp(S[i].stats_off), ntiles_of(L, SR[i]), S[i].C};
       a.Ctot = Ctot;
       a.groups = groups;
       a.inv_count = 1.0 / ((double)(Ctot / groups) * (double)L);
@@ -274,6 +279,11 @@ class Builder {
     const TensorH O = out;
     const bool has_skip = skip != nullptr;
     const TensorH K = skip ? *skip : TensorH{};
+    int dmax = 0;
+    for (auto& g : segs)
+      if (g.ntaps == 3 && g.dil > dmax) dmax = g.dil;
+    const int tile_rows = conv_tile_rows(dmax, Cout, m_->cfg.precision);
+    if (out.has_stats) tile_rows_[out.id] = tile_rows;
     // cost
     double ktot = 0;
     double conv_elems = 0, conv_f32 = 0;
@@ -321,7 +331,8 @@ class Builder {
       a.out = self->act(O.off);
       a.out_f32 = O.f32 ? 1 : 0;
       a.stats = O.has_stats ? self->statp(O.stats_off) : nullptr;
-      a.ntiles = ntiles_of(a.Lout);
+      a.ntiles = ntiles_of(a.Lout, tile_rows);
+      a.tile_rows = tile_rows;
       return launch_conv(a, c.B, prec, c.st);
     });
   }
@@ -450,6 +461,7 @@ class Builder {
   int next_id_ = 0;
   std::map<int, size_t> sizes_, offs_;
   std::map<int, int> refs_;
+  std::map<int, int> tile_rows_;  // rows per statistics tile of each tensor (set by its producer)
   std::vector<std::pair<size_t, size_t>> free_;
 };
 
