@@ -82,7 +82,7 @@ struct IterGeom {
 };
 
 template <typename T, bool X3, int WN, int HALO, bool SKIPV, int WGN, int WM>
-__global__ __launch_bounds__(256 * WGN) void conv_mfma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs a) {
   constexpr int TT = 4 * WM * 32;  // staged rows: 4 waves along time x WM MFMA tiles of 32 rows
   constexpr int NTH = 256 * WGN;  // 4 waves along time x WGN waves along output channels
   constexpr int NPF = (TT * 4) / NTH;  // prefetched (row, octet) items per thread: exactly the 256 staged rows x 4 octets
@@ -108,13 +108,16 @@ __global__ __launch_bounds__(256 * WGN) void conv_mfma_kernel(const ConvArgs a) 
   const int l31 = lane & 31;
   const int khalf = (lane >> 5) * 16;
 
+  // accumulators start at the bias of the lane's output channel (an accumulator lane owns one channel)
   f32x16 acc[WM][WN];
 #pragma unroll
-  for (int i = 0; i < WM; ++i)
+  for (int j = 0; j < WN; ++j) {
+    const float bj = a.bias[co0 + (wvn * WN + j) * 32 + (lane & 31)];
 #pragma unroll
-    for (int j = 0; j < WN; ++j)
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = bj;
+  }
 
   int niter = 0;
   for (int s = 0; s < a.nseg; ++s) niter += a.seg[s].C >> 5;
@@ -188,14 +191,19 @@ __global__ __launch_bounds__(256 * WGN) void conv_mfma_kernel(const ConvArgs a) 
 #pragma unroll
       for (int i = 0; i < NPF; ++i) {
         const int r = (tid >> 2) + (NTH / 4) * i;
-        const int tm = g.base_time + r;
         if (r < g.nrows) {
-          f32x8 v = f32x8_zero();
-          if (tm >= 0 && tm < g.row_bound) {
-            v = ra[i].get();
-            if (g.xform) v = affine_gelu<X3>(v, sc, sh);
-          }
+          f32x8 v = ra[i].get();
+          if (g.xform) v = affine_gelu<X3>(v, sc, sh);
           put_row<X3>(act_hi, act_lo, r * ROWB + oct * 16, v);
+        }
+      }
+      // zero padding of the convolution: only tiles that touch a sequence end have rows outside [0, row_bound)
+      if (g.base_time < 0 || g.base_time + g.nrows > g.row_bound) {
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+          const int r = (tid >> 2) + (NTH / 4) * i;
+          const int tm = g.base_time + r;
+          if (r < g.nrows && (tm < 0 || tm >= g.row_bound)) put_row<X3>(act_hi, act_lo, r * ROWB + oct * 16, f32x8_zero());
         }
       }
     } else {  // avg-pool segments (8 of 130 convs): staged synchronously, two source rows per LDS row
@@ -323,14 +331,13 @@ __global__ __launch_bounds__(256 * WGN) void conv_mfma_kernel(const ConvArgs a) 
       }
   __syncthreads();
 
-  const f32x8 bias8 = Elem<float>::load8(a.bias + cg);
   f32x8 s1 = f32x8_zero(), s2 = f32x8_zero();
 #pragma unroll
   for (int i = 0; i < NEP; ++i) {
     const int r = r0 + RPP * i;
     const int tm = t0 + r;
     if (r < TTO && tm < a.Lout) {
-      f32x8 v = Elem<float>::load8(ost + r * OS + eoct * 8) + bias8;
+      f32x8 v = Elem<float>::load8(ost + r * OS + eoct * 8);
       if (skip_pf) {
         v += rsk[SKIP_PF ? i : 0].get();
       } else if (skip_b) {
