@@ -110,7 +110,7 @@ int launch_gn_prepare(const GnArgs& a, int B, hipStream_t st);
 struct TimeEmbedArgs {  // wavegrad.py:359-373 + unet.py:41-45, 133-135
   const float* ts;      // [B]
   const float* freqs;   // [E/2]
-  const float *w1, *b1; // [E][E], [E]   time_embed.proj
+  const float *w1, *b1; // [E in][E out] (TRANSPOSED), [E]   time_embed.proj
   const float *w2, *b2; // time_embed_extra.1
   const float* class_embed;  // [num_labels][E] or nullptr
   const int64_t* labels;     // [B] or nullptr
@@ -124,7 +124,7 @@ int launch_gelu_rows(const float* in, float* out, int n, hipStream_t st);
 
 struct FilmArgs {  // all blocks' cond_layers Linear at once: film[b][r] = bias[r] + W[r] . gemb[b]
   const float* gemb;  // [B][E]
-  const float* w;     // [R][E]
+  const float* w;     // [E][R] (TRANSPOSED)
   const float* bias;  // [R]
   float* film;        // [B][R]
   int E, R;

@@ -220,9 +220,10 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// w1 / w2 are stored TRANSPOSED ([in][out]) so that thread r's reads of column r coalesce across the wave.
 __global__ __launch_bounds__(256) void time_embed_kernel(const TimeEmbedArgs a) {
   __shared__ float e0[1024], e1[1024];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   const int b = blockIdx.x;
   const int E = a.E, half = E >> 1;
   const float t = a.ts[b];
@@ -232,11 +233,15 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const TimeEmbedArgs a) 
     e0[half + j] = sinf(arg);
   }
   __syncthreads();
-  for (int r = wave; r < E; r += 4) {  // time_embed.proj
-    float acc = 0.f;
-    for (int j = lane; j < E; j += 64) acc = fmaf(a.w1[(size_t)r * E + j], e0[j], acc);
-    acc = wave_sum(acc);
-    if (lane == 0) e1[r] = gelu_f(acc + a.b1[r]);  // time_embed_extra.0 = GELU
+  for (int r = tid; r < E; r += 256) {  // time_embed.proj, then time_embed_extra.0 = GELU
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    for (int j = 0; j < E; j += 4) {
+      acc0 = fmaf(a.w1[(size_t)(j + 0) * E + r], e0[j + 0], acc0);
+      acc1 = fmaf(a.w1[(size_t)(j + 1) * E + r], e0[j + 1], acc1);
+      acc2 = fmaf(a.w1[(size_t)(j + 2) * E + r], e0[j + 2], acc2);
+      acc3 = fmaf(a.w1[(size_t)(j + 3) * E + r], e0[j + 3], acc3);
+    }
+    e1[r] = gelu_f((acc0 + acc1) + (acc2 + acc3) + a.b1[r]);
   }
   __syncthreads();
   const float* ce = nullptr;
@@ -246,16 +251,18 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const TimeEmbedArgs a) 
     if (lab >= a.num_labels) lab = a.num_labels - 1;
     ce = a.class_embed + (size_t)lab * E;
   }
-  for (int r = wave; r < E; r += 4) {  // time_embed_extra.1
-    float acc = 0.f;
-    for (int j = lane; j < E; j += 64) acc = fmaf(a.w2[(size_t)r * E + j], e1[j], acc);
-    acc = wave_sum(acc);
-    if (lane == 0) {
-      float v = acc + a.b2[r];
-      if (ce) v += ce[r];
-      a.emb[(size_t)b * E + r] = v;
-      a.gemb[(size_t)b * E + r] = gelu_f(v);
+  for (int r = tid; r < E; r += 256) {  // time_embed_extra.1 (+ class embedding)
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    for (int j = 0; j < E; j += 4) {
+      acc0 = fmaf(a.w2[(size_t)(j + 0) * E + r], e1[j + 0], acc0);
+      acc1 = fmaf(a.w2[(size_t)(j + 1) * E + r], e1[j + 1], acc1);
+      acc2 = fmaf(a.w2[(size_t)(j + 2) * E + r], e1[j + 2], acc2);
+      acc3 = fmaf(a.w2[(size_t)(j + 3) * E + r], e1[j + 3], acc3);
     }
+    float v = (acc0 + acc1) + (acc2 + acc3) + a.b2[r];
+    if (ce) v += ce[r];
+    a.emb[(size_t)b * E + r] = v;
+    a.gemb[(size_t)b * E + r] = gelu_f(v);
   }
 }
 
@@ -264,24 +271,47 @@ __global__ void gelu_rows_kernel(const float* in, float* out, int n) {
   if (i < n) out[i] = gelu_f(in[i]);
 }
 
-// film[b][r] = bias[r] + W[r] . gemb[b]; one wave per output row, all clips.
-template <int N>  // N = E / 64
-__global__ __launch_bounds__(256) void film_kernel(const FilmArgs a, int B) {
-  const int lane = threadIdx.x & 63;
-  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= a.R) return;
+// film[b][r] = bias[r] + W[r] . gemb[b].  W is stored TRANSPOSED ([E][R]): thread = one output row r (coalesced
+// weight reads), 32 clips accumulated in registers per pass, gemb staged in LDS as [e][32 clips].
+constexpr int FILM_NB = 32;
+__global__ __launch_bounds__(128) void film_kernel(const FilmArgs a, int B) {
+  __shared__ __attribute__((aligned(16))) float g[1024 * FILM_NB];
+  const int r = blockIdx.x * 128 + threadIdx.x;
   const int E = a.E;
-  float w[N];
+  for (int b0 = 0; b0 < B; b0 += FILM_NB) {
+    const int nb = min(FILM_NB, B - b0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < E * FILM_NB; i += 128) {
+      const int e = i / FILM_NB, bb = i % FILM_NB;
+      g[i] = bb < nb ? a.gemb[(size_t)(b0 + bb) * E + e] : 0.f;
+    }
+    __syncthreads();
+    if (r < a.R) {
+      float acc[FILM_NB];
 #pragma unroll
-  for (int i = 0; i < N; ++i) w[i] = a.w[(size_t)r * E + i * 64 + lane];
-  const float bias = a.bias[r];
-  for (int b = 0; b < B; ++b) {
-    const float* g = a.gemb + (size_t)b * E;
-    float acc = 0.f;
+      for (int k = 0; k < FILM_NB; ++k) acc[k] = 0.f;
+      for (int e0 = 0; e0 < E; e0 += 8) {
+        float w[8];
 #pragma unroll
-    for (int i = 0; i < N; ++i) acc = fmaf(w[i], g[i * 64 + lane], acc);
-    acc = wave_sum(acc);
-    if (lane == 0) a.film[(size_t)b * a.R + r] = acc + bias;
+        for (int u = 0; u < 8; ++u) w[u] = a.w[(size_t)(e0 + u) * a.R + r];  // 8 independent loads in flight
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const f32x4* gp = reinterpret_cast<const f32x4*>(&g[(e0 + u) * FILM_NB]);
+#pragma unroll
+          for (int q = 0; q < FILM_NB / 4; ++q) {
+            const f32x4 gv = gp[q];
+            acc[4 * q + 0] = fmaf(w[u], gv[0], acc[4 * q + 0]);
+            acc[4 * q + 1] = fmaf(w[u], gv[1], acc[4 * q + 1]);
+            acc[4 * q + 2] = fmaf(w[u], gv[2], acc[4 * q + 2]);
+            acc[4 * q + 3] = fmaf(w[u], gv[3], acc[4 * q + 3]);
+          }
+        }
+      }
+      const float bias = a.bias[r];
+#pragma unroll
+      for (int k = 0; k < FILM_NB; ++k)
+        if (k < nb) a.film[(size_t)(b0 + k) * a.R + r] = acc[k] + bias;
+    }
   }
 }
 
@@ -429,15 +459,8 @@ int launch_gelu_rows(const float* in, float* out, int n, hipStream_t st) {
 }
 
 int launch_film(const FilmArgs& a, int B, hipStream_t st) {
-  const dim3 grid((a.R + 3) / 4), blk(256);
-  switch (a.E) {
-    case 64: hipLaunchKernelGGL(film_kernel<1>, grid, blk, 0, st, a, B); break;
-    case 128: hipLaunchKernelGGL(film_kernel<2>, grid, blk, 0, st, a, B); break;
-    case 256: hipLaunchKernelGGL(film_kernel<4>, grid, blk, 0, st, a, B); break;
-    case 512: hipLaunchKernelGGL(film_kernel<8>, grid, blk, 0, st, a, B); break;
-    case 1024: hipLaunchKernelGGL(film_kernel<16>, grid, blk, 0, st, a, B); break;
-    default: VQVS_FAIL(-1, "film: unsupported E=%d", a.E);
-  }
+  if (a.E > 1024 || a.E < 8 || a.E % 8) VQVS_FAIL(-1, "film: unsupported E=%d", a.E);
+  hipLaunchKernelGGL(film_kernel, dim3((a.R + 127) / 128), dim3(128), 0, st, a, B);
   VQVS_HIP(hipGetLastError());
   return 0;
 }

@@ -153,6 +153,13 @@ class Builder {
     if (it == pidx_.end()) return nullptr;
     return hp_[it->second];
   }
+  // [rows][cols] host matrix uploaded as [cols][rows]
+  size_t blob_f32_transposed(const float* w, int rows, int cols) {
+    std::vector<float> t((size_t)rows * cols);
+    for (int r = 0; r < rows; ++r)
+      for (int c = 0; c < cols; ++c) t[(size_t)c * rows + r] = w[(size_t)r * cols + c];
+    return blob.add(t.data(), t.size() * 4);
+  }
   size_t blob_f32(const std::string& name) {
     auto it = pidx_.find(name);
     return blob.add(hp_[it->second], m_->params[it->second].numel() * 4);
@@ -347,7 +354,7 @@ class Builder {
     const int out_shift = in_shift + (s.resize == RESIZE_AVG2 ? 1 : (s.resize == RESIZE_UP2 ? -1 : 0));
     // With 64-channel output tiles every co-tile workgroup repeats the GroupNorm/GELU prologue of the same
     // input rows; from 4 tiles up (Cout >= 256: only the short, deep levels) it is cheaper to run it once.
-    const bool pre_xform = cout >= 256;
+    const bool pre_xform = cout >= 512;
     // GroupNorm 1 coefficients over the (virtually concatenated) input
     const size_t ss1 = alloc_ss(cin);
     add_gn(ins, pre + "pre_cond.0.0", false, 0, 0, 0, ss1);
@@ -567,7 +574,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
     if (E) {
       const size_t gemb = b.alloc_misc((size_t)c.max_batch * E);
       film_misc = b.alloc_misc((size_t)c.max_batch * 2 * c.rb_cout);
-      const size_t w_off = b.blob_f32("cond_layers.1.weight");
+      const size_t w_off = b.blob_f32_transposed(b.P("cond_layers.1.weight"), 2 * c.rb_cout, E);
       const size_t bias_off = b.blob_f32("cond_layers.1.bias");
       const int R = 2 * c.rb_cout;
       m->meta.push_back({"film", "", 0, 0, 0});
@@ -595,8 +602,8 @@ int build_model(vqvs_model* m, const float* const* hp) {
     for (int i = 0; i < E / 2; ++i)  // wavegrad.py:361-369 (float32 tensor math)
       freqs[i] = (float)(std::exp((double)(float)(-std::log(100.0 / 0.1)) * (double)i / (double)(E / 2 - 1))) * 100.0f;
     const size_t freq_off = b.blob.add(freqs.data(), freqs.size() * 4);
-    const size_t w1 = b.blob_f32("time_embed.proj.weight"), b1 = b.blob_f32("time_embed.proj.bias");
-    const size_t w2 = b.blob_f32("time_embed_extra.1.weight"), b2 = b.blob_f32("time_embed_extra.1.bias");
+    const size_t w1 = b.blob_f32_transposed(b.P("time_embed.proj.weight"), E, E), b1 = b.blob_f32("time_embed.proj.bias");
+    const size_t w2 = b.blob_f32_transposed(b.P("time_embed_extra.1.weight"), E, E), b2 = b.blob_f32("time_embed_extra.1.bias");
     const size_t ce = c.num_labels > 0 ? b.blob_f32("class_embed.weight") : 0;
     const size_t emb_off = b.alloc_misc((size_t)c.max_batch * E);
     const size_t gemb_off = b.alloc_misc((size_t)c.max_batch * E);
@@ -634,7 +641,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
       ball.insert(ball.end(), bb, bb + rows);
       R += rows;
     }
-    const size_t wall_off = b.blob.add(Wall.data(), Wall.size() * 4);
+    const size_t wall_off = b.blob_f32_transposed(Wall.data(), R, E);
     const size_t ball_off = b.blob.add(ball.data(), ball.size() * 4);
     const size_t film_off = b.alloc_misc((size_t)c.max_batch * R);
     m->meta.push_back({"film", "", 0, 0, 0});
