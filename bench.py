@@ -57,7 +57,7 @@ def cpu_baseline(base: int, T: int, sample_steps: int):
     cfg = _native.Cfg()
     cfg.kind, cfg.base_channels, cfg.in_channels, cfg.out_channels = 0, base, 1, 1
     sd = {"predictor." + n: det_tensor("predictor." + n, s) for n, s in _native.param_table(cfg)}
-    nb, ns = (2, 2) if base == 64 else (2, 4)
+    nb, ns = (4, 6) if base == 64 else (4, 12)  # ~10-20 s of CPU work on 32 threads
     g = torch.Generator().manual_seed(0)
     x = torch.randn(nb, 1, T, generator=g)
     noises = [torch.randn(nb, 1, T, generator=g) for _ in range(ns)]
@@ -104,6 +104,12 @@ def main():
     begin, end = shard_range(n_total, rank, n_gpus)
     seed = 1234
 
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
     def one_step(step_id: int):
         x_T = randn_clips(end - begin, a.T, dev, seed + step_id, clip_offset=begin)
         torch.cuda.synchronize()
@@ -114,12 +120,10 @@ def main():
                                          seed=seed + step_id, clip_offset=begin)
         return gather_clips(x0, n_total, a.T)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
-            torch.cuda.synchronize()
-
+    # one-time initialisation outside any step: pack/upload the weights, size the arena, set kernel attributes
+    model.predictor.handle(dev, end - begin, a.T)
+    model.predictor(randn_clips(end - begin, a.T, dev, 1), torch.full((end - begin,), 0.5, device=dev))
+    barrier()
     for w in range(a.warmup):
         run(one_step(w), w)
     inputs = [one_step(100 + k) for k in range(a.steps)]

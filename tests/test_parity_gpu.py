@@ -225,3 +225,27 @@ def test_counter_rng_is_standard_normal(dev):
     assert abs(x.mean().item()) < 5e-3 and abs(x.var().item() - 1) < 1e-2
     assert abs((x ** 4).mean().item() - 3) < 5e-2
     assert torch.equal(randn_clips(2, 4096, dev, 5, clip_offset=3).cpu(), randn_clips(5, 4096, dev, 5).cpu()[3:5])
+
+
+def test_decode_uncond_guidance_vs_oracle(dev):
+    """vq_vae.py:147-220 (3x-batch classifier-free-style guidance) against the same composition on the oracle."""
+    model = det_model(VQVAE(base_channels=32, pred_name="unet", num_labels=4))
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    codes = torch.randint(0, 512, (2, 8), generator=torch.Generator().manual_seed(3))
+    labels = torch.tensor([0, 2])
+    x_T = seeded((2, 1, 2048), 4)
+    gen = torch.Generator().manual_seed(5)
+    noises = [torch.randn(x_T.shape, generator=gen) for _ in range(3)]
+    cond = ref_cpu.vq_embed(sd["vq.dictionary"], codes)
+    cond3 = torch.cat([cond, torch.zeros_like(cond), cond])
+    lab3 = torch.cat([labels + 1, labels + 1, torch.zeros_like(labels)])
+
+    def pred(xs, ts):
+        o = ref_cpu.unet_predictor(sd, 32, torch.cat([xs] * 3), torch.cat([ts] * 3), cond=cond3, labels=lab3)
+        base = o[:2]
+        return base + 1.5 * (base - o[2:4]) + 0.7 * (base - o[4:6])
+
+    want = ref_cpu.ddpm_sample("exp", x_T, pred, 3, noises, constrain=True)
+    got = model.decode_uncond_guidance(codes.to(dev), labels.to(dev), steps=3, constrain=True, vq_scale=1.5, label_scale=0.7,
+                                       x_T=x_T.to(dev), noise=[n.to(dev) for n in noises]).cpu()
+    assert rms(got - want) < WAVE_RMS

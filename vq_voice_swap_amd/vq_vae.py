@@ -74,6 +74,54 @@ class VQVAE(DiffusionModel):
             x_T, lambda xs, ts, **kw: self.predictor(xs, ts, cond=cond_seq, labels=labels, **kw),
             steps=steps, progress=progress, constrain=constrain, cond_fn=cond_fn, seed=seed, **kwargs)
 
+    def decode_uncond_guidance(self, codes: torch.Tensor, labels: Optional[torch.Tensor] = None, steps: int = 100,
+                               progress: bool = False, constrain: bool = False, label_scale: float = 0.0, vq_scale: float = 0.0,
+                               x_T: Optional[torch.Tensor] = None, **kwargs) -> torch.Tensor:
+        """Decode with classifier-free-style guidance towards the VQ codes and/or the label (reference
+        vq_vae.py:147-220): the predictor runs on a 1x-3x batch [conditional | codes dropped | label dropped] and the
+        prediction is base + scale * (base - dropped).  Labels are NOT offset by the caller: label 0 is the
+        unconditional label of such a model, so `labels + 1` is used as in the reference."""
+        if codes.dim() == 2:
+            cond_seq = self.vq.embed(codes)
+        elif codes.dim() == 3:
+            cond_seq = codes
+        else:
+            raise ValueError(f"unsupported codes shape: {codes.shape}")
+        n = cond_seq.shape[0]
+        T = codes.shape[-1] * self.encoder.downsample_rate
+        seed = kwargs.pop("seed", None)
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        if x_T is None:
+            x_T = randn_clips(n, T, codes.device, seed, kwargs.get("clip_offset", 0))
+
+        use_vq = bool(vq_scale)
+        use_label = labels is not None and bool(label_scale)
+        reps = 1 + int(use_vq) + int(use_label)
+        cond_batch = [cond_seq]
+        label_batch = [labels + 1] if labels is not None else None
+        if use_vq:
+            cond_batch.append(torch.zeros_like(cond_seq))
+            if label_batch is not None:
+                label_batch.append(labels + 1)
+        if use_label:
+            cond_batch.append(cond_seq)
+            label_batch.append(torch.zeros_like(labels))
+        cond_batch = torch.cat(cond_batch, dim=0)
+        label_batch = torch.cat(label_batch, dim=0) if label_batch is not None else None
+
+        def pred_fn(xs, ts):
+            outs = self.predictor(torch.cat([xs] * reps, dim=0), torch.cat([ts] * reps, dim=0), cond=cond_batch, labels=label_batch)
+            base = outs[:n]
+            pred, k = base, 1
+            for flag, scale in ((use_vq, vq_scale), (use_label, label_scale)):
+                if flag:
+                    pred = pred + scale * (base - outs[k * n:(k + 1) * n])
+                    k += 1
+            return pred
+
+        return self.diffusion.ddpm_sample(x_T, pred_fn, steps=steps, progress=progress, constrain=constrain, seed=seed, **kwargs)
+
     @property
     def downsample_rate(self) -> int:
         import math
