@@ -55,21 +55,32 @@ __device__ __forceinline__ f32x8 affine_gelu(f32x8 v, const f32x8& sc, const f32
   return r;
 }
 
-// raw (untransformed) octet as it sits in HBM
+// raw (untransformed) octet as it sits in HBM, fetched with a buffer load: the address is
+// (wave-uniform descriptor, per-lane 32-bit byte offset) -- no 64-bit per-lane arithmetic -- and an offset
+// outside [0, num_records) (rows before the start / after the end of the clip) simply returns zeros.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 template <typename T> struct Raw8;
 template <> struct Raw8<float> {
-  f32x4 a, b;
-  __device__ __forceinline__ void load(const float* p) {
-    a = *reinterpret_cast<const f32x4*>(p);
-    b = *reinterpret_cast<const f32x4*>(p + 4);
+  u32x4 a, b;
+  __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, int off) {
+    a = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    b = __builtin_amdgcn_raw_buffer_load_b128(r, off + 16, 0, 0);
   }
-  __device__ __forceinline__ f32x8 get() const { return f32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
+  __device__ __forceinline__ f32x8 get() const {
+    const f32x4 x = __builtin_bit_cast(f32x4, a), y = __builtin_bit_cast(f32x4, b);
+    return f32x8{x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+  }
 };
 template <> struct Raw8<bf16_t> {
-  bf16x8 a;
-  __device__ __forceinline__ void load(const bf16_t* p) { a = *reinterpret_cast<const bf16x8*>(p); }
-  __device__ __forceinline__ f32x8 get() const { return __builtin_convertvector(a, f32x8); }
+  u32x4 a;
+  __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, int off) { a = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0); }
+  __device__ __forceinline__ f32x8 get() const { return __builtin_convertvector(__builtin_bit_cast(bf16x8, a), f32x8); }
 };
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, long long bytes) {
+  const int n = bytes > 0x7fffffffLL ? 0x7fffffff : (int)bytes;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, n, 0x00020000);
+}
 
 // everything a thread needs to know about one K iteration (segment, chunk)
 struct IterGeom {
@@ -108,6 +119,23 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
   const int l31 = lane & 31;
   const int khalf = (lane >> 5) * 16;
 
+  // ---- per-thread invariants of the staging loops (hoisted out of the K loop) ----
+  int act_lds[NPF];   // LDS byte offset of (row r_i, octet)
+#pragma unroll
+  for (int i = 0; i < NPF; ++i) act_lds[i] = ((tid >> 2) + (NTH / 4) * i) * ROWB + oct * 16;
+  int w_lds[NWV], w_goff[NWV];  // LDS byte offset / global byte offset (within one chunk block) of weight piece i
+#pragma unroll
+  for (int i = 0; i < NWV; ++i) {
+    const int idx = tid + NTH * i;
+    const int row = idx >> 2, q = idx & 3;
+    const int tap = row / CT, col = row - tap * CT;
+    w_lds[i] = row * ROWB + q * 16;
+    w_goff[i] = ((tap * a.Cout + co0 + col) * 32 + q * 8) * 2;
+  }
+  const __amdgpu_buffer_rsrc_t rs_wh = make_rsrc(a.w_hi, a.w_bytes);
+  const __amdgpu_buffer_rsrc_t rs_wl = make_rsrc(X3 ? a.w_lo : a.w_hi, a.w_bytes);
+  (void)rs_wl;
+
   // accumulators start at the bias of the lane's output channel (an accumulator lane owns one channel)
   f32x16 acc[WM][WN];
 #pragma unroll
@@ -141,7 +169,7 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
   // ---- prefetch registers -------------------------------------------------------------
   Raw8<T> ra[NPF];
   f32x4 rss[4];
-  bf16x8 rwh[NWV], rwl[NWV];
+  u32x4 rwh[NWV], rwl[NWV];
   (void)rwl;
 
   auto issue_loads = [&](const IterGeom& g) {
@@ -153,25 +181,21 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
       for (int j = 0; j < 4; ++j) rss[j] = *reinterpret_cast<const f32x4*>(p + 2 * j);
     }
     if (!g.avg) {
-      const T* const src_c = reinterpret_cast<const T*>(sg.src) + (size_t)b * sg.Lsrc * sg.Csrc + sg.c0 + cl;
+      // byte offset of item i = ((base_time + r_i) * Csrc + c0 + cl) * sizeof(T); negative or past-the-end rows
+      // fall outside the descriptor and read as zero (their LDS rows are re-zeroed after the prologue anyway)
+      const __amdgpu_buffer_rsrc_t rs =
+          make_rsrc(reinterpret_cast<const T*>(sg.src) + (size_t)b * sg.Lsrc * sg.Csrc, (long long)sg.Lsrc * sg.Csrc * (int)sizeof(T));
+      const int row_bytes = sg.Csrc * (int)sizeof(T);
+      const int base = (g.base_time * sg.Csrc + sg.c0 + cl) * (int)sizeof(T) + (tid >> 2) * row_bytes;
+      const int step = (NTH / 4) * row_bytes;
 #pragma unroll
-      for (int i = 0; i < NPF; ++i) {
-        const int r = (tid >> 2) + (NTH / 4) * i;
-        const int tm = g.base_time + r;
-        if (r < g.nrows && tm >= 0 && tm < g.row_bound) ra[i].load(src_c + (size_t)tm * sg.Csrc);
-      }
+      for (int i = 0; i < NPF; ++i) ra[i].load(rs, base + i * step);
     }
-    const int nvec = g.ntaps * CT * 4;
+    const int wbase = (int)((sg.w_off + (long long)g.ch * g.ntaps * a.Cout * 32) * 2);
 #pragma unroll
     for (int i = 0; i < NWV; ++i) {
-      const int idx = tid + NTH * i;
-      if (idx < nvec) {
-        const int row = idx >> 2, q = idx & 3;
-        const int tap = row / CT, col = row - tap * CT;
-        const long long e = sg.w_off + ((long long)((g.ch * g.ntaps + tap) * a.Cout + co0 + col)) * 32 + q * 8;
-        rwh[i] = *reinterpret_cast<const bf16x8*>(a.w_hi + e);
-        if constexpr (X3) rwl[i] = *reinterpret_cast<const bf16x8*>(a.w_lo + e);
-      }
+      rwh[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_wh, w_goff[i] + wbase, 0, 0);
+      if constexpr (X3) rwl[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_wl, w_goff[i] + wbase, 0, 0);
     }
   };
 
@@ -192,9 +216,13 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
       for (int i = 0; i < NPF; ++i) {
         const int r = (tid >> 2) + (NTH / 4) * i;
         if (r < g.nrows) {
-          f32x8 v = ra[i].get();
-          if (g.xform) v = affine_gelu<X3>(v, sc, sh);
-          put_row<X3>(act_hi, act_lo, r * ROWB + oct * 16, v);
+          if (!X3 && !g.xform) {  // raw bf16 segment: the bits go to LDS untouched
+            *reinterpret_cast<u32x4*>(act_hi + act_lds[i]) = ra[i].a;
+          } else {
+            f32x8 v = ra[i].get();
+            if (g.xform) v = affine_gelu<X3>(v, sc, sh);
+            put_row<X3>(act_hi, act_lo, act_lds[i], v);
+          }
         }
       }
       // zero padding of the convolution: only tiles that touch a sequence end have rows outside [0, row_bound)
@@ -203,7 +231,7 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
         for (int i = 0; i < NPF; ++i) {
           const int r = (tid >> 2) + (NTH / 4) * i;
           const int tm = g.base_time + r;
-          if (r < g.nrows && (tm < 0 || tm >= g.row_bound)) put_row<X3>(act_hi, act_lo, r * ROWB + oct * 16, f32x8_zero());
+          if (r < g.nrows && (tm < 0 || tm >= g.row_bound)) put_row<X3>(act_hi, act_lo, act_lds[i], f32x8_zero());
         }
       }
     } else {  // avg-pool segments (8 of 130 convs): staged synchronously, two source rows per LDS row
@@ -222,14 +250,12 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
         put_row<X3>(act_hi, act_lo, r * ROWB + oct * 16, v);
       }
     }
-    const int nvec = g.ntaps * CT * 4;
+    // weights: every piece is written (1-tap segments leave garbage in the unused tap rows)
 #pragma unroll
     for (int i = 0; i < NWV; ++i) {
-      const int idx = tid + NTH * i;
-      if (idx < nvec) {
-        const int row = idx >> 2, q = idx & 3;
-        *reinterpret_cast<bf16x8*>(w_hi + row * ROWB + q * 16) = rwh[i];
-        if constexpr (X3) *reinterpret_cast<bf16x8*>(w_lo + row * ROWB + q * 16) = rwl[i];
+      if (NWV * NTH == 3 * CT * 4 || tid + NTH * i < 3 * CT * 4) {
+        *reinterpret_cast<u32x4*>(w_hi + w_lds[i]) = rwh[i];
+        if constexpr (X3) *reinterpret_cast<u32x4*>(w_lo + w_lds[i]) = rwl[i];
       }
     }
   };
@@ -239,28 +265,30 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
     const char* const act_lo = act_hi + ACT_BYTES;
     const char* const w_hi = act_hi + PLANES * ACT_BYTES;
     const char* const w_lo = w_hi + W_BYTES;
+    int wb[WN];  // B-fragment (weights) byte offsets: constant per lane
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt) wb[nt] = ((wvn * WN + nt) * 32 + l31) * ROWB + khalf;
     for (int k = 0; k < g.ntaps; ++k) {
       const int toff = (g.ntaps == 3) ? (k - 1) * g.d : 0;
-      int arow[WM];
+      int ab[WM];  // A-fragment (activation) byte offsets for this tap
 #pragma unroll
       for (int mt = 0; mt < WM; ++mt) {
         const int tl = wave * (WM * 32) + mt * 32 + l31;
-        arow[mt] = g.up ? (((tl + toff) >> 1) + 1) : (tl + toff + g.d);
+        ab[mt] = (g.up ? (((tl + toff) >> 1) + 1) : (tl + toff + g.d)) * ROWB + khalf;
       }
+      const int wk = k * CT * ROWB;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        const int kb = ks * 32 + khalf;
         bf16x8 ah[WM], al[WM], bh[WN], bl[WN];
 #pragma unroll
         for (int mt = 0; mt < WM; ++mt) {
-          ah[mt] = *reinterpret_cast<const bf16x8*>(act_hi + arow[mt] * ROWB + kb);
-          if constexpr (X3) al[mt] = *reinterpret_cast<const bf16x8*>(act_lo + arow[mt] * ROWB + kb);
+          ah[mt] = *reinterpret_cast<const bf16x8*>(act_hi + ab[mt] + ks * 32);
+          if constexpr (X3) al[mt] = *reinterpret_cast<const bf16x8*>(act_lo + ab[mt] + ks * 32);
         }
 #pragma unroll
         for (int nt = 0; nt < WN; ++nt) {
-          const int wrow = k * CT + (wvn * WN + nt) * 32 + l31;
-          bh[nt] = *reinterpret_cast<const bf16x8*>(w_hi + wrow * ROWB + kb);
-          if constexpr (X3) bl[nt] = *reinterpret_cast<const bf16x8*>(w_lo + wrow * ROWB + kb);
+          bh[nt] = *reinterpret_cast<const bf16x8*>(w_hi + wk + wb[nt] + ks * 32);
+          if constexpr (X3) bl[nt] = *reinterpret_cast<const bf16x8*>(w_lo + wk + wb[nt] + ks * 32);
         }
 #pragma unroll
         for (int mt = 0; mt < WM; ++mt)
@@ -288,6 +316,9 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
   const T* const skip_b = a.skip ? reinterpret_cast<const T*>(a.skip) + (size_t)b * a.skip_L * a.skip_C + cg : nullptr;
   const bool skip_pf = SKIP_PF && skip_b != nullptr && a.skip_resize != RESIZE_AVG2;
   Raw8<T> rsk[SKIP_PF ? NEP : 1];
+  const __amdgpu_buffer_rsrc_t rs_skip = make_rsrc(
+      a.skip ? reinterpret_cast<const T*>(a.skip) + (size_t)b * a.skip_L * a.skip_C : reinterpret_cast<const T*>(a.bias),
+      a.skip ? (long long)a.skip_L * a.skip_C * (int)sizeof(T) : 0);
 
   // ------------------------------ pipelined K loop ------------------------------
   {
@@ -307,7 +338,8 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
 #pragma unroll
         for (int i = 0; i < (SKIP_PF ? NEP : 1); ++i) {
           const int tm = t0 + r0 + RPP * i;
-          if (r0 + RPP * i < TTO && tm < a.Lout) rsk[i].load(skip_b + (size_t)(a.skip_resize == RESIZE_UP2 ? (tm >> 1) : tm) * a.skip_C);
+          const int ts = a.skip_resize == RESIZE_UP2 ? (tm >> 1) : tm;
+          rsk[i].load(rs_skip, (ts * a.skip_C + cg) * (int)sizeof(T));  // rows past the end read as zero and are never stored
         }
       }
       __syncthreads();

@@ -51,6 +51,7 @@ struct ConvArgs {
   int nseg;
   const bf16_t* w_hi;  // packed [segment][chunk of 32 ci][tap][Cout][32] (hi part of the bf16 split)
   const bf16_t* w_lo;  // lo part (VQVS_PREC_F32 only)
+  long long w_bytes;   // bytes of one packed plane (bounds of the weight buffer descriptor)
   const float* bias;   // [Cout]
   int Cout, Lout;
   const void* skip;  // identity-skip source [B][skip_L][skip_C] of T, or nullptr

@@ -279,6 +279,7 @@ class Builder {
     const size_t hi_off = blob.add(pk.hi.data(), pk.hi.size() * 2);
     const size_t lo_off = m_->cfg.precision == VQVS_PREC_F32 ? blob.add(pk.lo.data(), pk.lo.size() * 2) : 0;
     const size_t bias_off = blob.add(bias.data(), bias.size() * 4);
+    const long long w_bytes = (long long)pk.hi.size() * 2;
     const bool x3 = m_->cfg.precision == VQVS_PREC_F32;
     const int prec = m_->cfg.precision;
     Builder* self = this;
@@ -326,6 +327,7 @@ class Builder {
       }
       a.w_hi = reinterpret_cast<const bf16_t*>(self->wp(hi_off));
       a.w_lo = x3 ? reinterpret_cast<const bf16_t*>(self->wp(lo_off)) : nullptr;
+      a.w_bytes = w_bytes;
       a.bias = reinterpret_cast<const float*>(self->wp(bias_off));
       a.Cout = Cout;
       a.Lout = shiftL(c.Lbase, O.lshift);
