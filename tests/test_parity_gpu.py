@@ -249,3 +249,32 @@ def test_decode_uncond_guidance_vs_oracle(dev):
     got = model.decode_uncond_guidance(codes.to(dev), labels.to(dev), steps=3, constrain=True, vq_scale=1.5, label_scale=0.7,
                                        x_T=x_T.to(dev), noise=[n.to(dev) for n in noises]).cpu()
     assert rms(got - want) < WAVE_RMS
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", FP32_REL), ("bf16", BF16_REL)])
+def test_resblock_config_sweep_vs_oracle(dev, prec, tol):
+    """Every kernel variant the schedule can pick (32/64/128-channel tiles, identity / 1x1 skip, avg / up resize,
+    small and large dilation halo, ragged lengths, several clips) against the oracle on seeded inputs."""
+    cases = [
+        # cin, cout, scale, dil, emb, L, B
+        (32, 32, 1.0, 1, 128, 300, 2),
+        (64, 128, 1.0, 2, 128, 700, 1),
+        (128, 128, 1.0, 2, 256, 253, 3),     # exactly one tile + 1 row
+        (128, 128, 0.5, 2, 128, 504, 2),     # avg-pool, identity skip
+        (128, 128, 2.0, 2, 128, 252, 2),     # upsample, identity skip
+        (256, 256, 1.0, 8, 256, 250, 2),     # big-halo variant, 128-channel tiles
+        (512, 512, 1.0, 32, 256, 250, 1),    # pre-transformed (raw) segments, dilation 32
+        (768, 256, 1.0, 2, 256, 500, 1),     # 1x1 skip conv over a wide input
+        (96, 32, 1.0, 2, None, 1000, 2),     # no FiLM, 32-channel tiles, 3 chunks
+        (160, 64, 1.0, 4, 128, 129, 2),      # odd chunk count, dilation 4
+    ]
+    for i, (cin, cout, scale, dil, emb, L, B) in enumerate(cases):
+        m = ResBlockModule(cin, emb, cout if cout != cin else None, scale, dil)
+        det_init_((f"sweep{i}." + k, v) for k, v in m.block.state_dict().items())
+        m.set_precision(prec)
+        x = seeded((B, cin, L), 1000 + i)
+        e = seeded((B, emb), 2000 + i) if emb else None
+        sd = {"b." + k: v.detach() for k, v in m.block.state_dict().items()}
+        want = ref_cpu.res_block(x, sd, "b", dict(cin=cin, cout=cout, scale=scale, dil=dil), e)
+        got = m(x.to(dev), None if e is None else e.to(dev)).cpu()
+        assert got.shape == want.shape and rel_rms(got, want) < tol, (i, cin, cout, scale, dil, L, B, rel_rms(got, want))
