@@ -269,6 +269,27 @@ def gen_vqvae():
     save("f8_vqvae_decode", x_T_seed=51, noise_seed=52, codes16=codes[:, :16], labels=labels, x0=dec)
 
 
+# ---------------------------------------------------------------- F9 classifier (config 5)
+def gen_classifier():
+    import torch.nn.functional as F
+    from vq_voice_swap.models import Classifier  # reference
+
+    clf = det_model(Classifier(num_labels=7, base_channels=32))
+    sd = state_of(clf)
+    x = seeded((2, 1, 64000), 61)
+    ts = torch.tensor([0.25, 0.8])
+    labels = torch.tensor([4, 1])
+    xg = x.clone().requires_grad_()
+    logits = clf(xg, ts)
+    grad = torch.autograd.grad(F.log_softmax(logits, dim=-1)[range(2), labels].sum(), xg)[0]
+    logits2 = ref_cpu.classifier(sd, 32, x, ts)
+    check("classifier logits", logits.detach(), logits2, tol=1e-6)
+    grad2 = ref_cpu.classifier_cond_fn(sd, 32, labels)(x, ts)
+    check("classifier grad", grad, grad2, tol=1e-6)
+    print(f"  logits rms={logits.pow(2).mean().sqrt().item():.4f} grad rms={grad.pow(2).mean().sqrt().item():.3e}")
+    save("f9_classifier32", x_seed=61, ts=ts, labels=labels, logits=logits.detach(), grad=grad)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     if not only or "resblocks" in only:
@@ -281,4 +302,6 @@ if __name__ == "__main__":
             gen_sampler(m, sd)
     if not only or "vqvae" in only:
         gen_vqvae()
+    if not only or "classifier" in only:
+        gen_classifier()
     print("ok")

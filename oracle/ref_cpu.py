@@ -196,6 +196,48 @@ def unet_encoder(sd: State, base: int, x: Tensor, prefix: str = "encoder") -> Te
     return F.conv1d(h, sd[p + ".out.1.weight"], sd[p + ".out.1.bias"], padding=1)
 
 
+def classifier(sd: State, base: int, x: Tensor, ts: Tensor, prefix: str = "") -> Tensor:
+    """Classifier.forward (models/classifier.py:31-36, 111-121, 153-158, 170-191): logits [N, num_labels]."""
+    p = prefix + "stem"
+    emb = time_embedding(ts, sd, p + ".time_embed")
+    emb = F.linear(F.gelu(emb), sd[p + ".time_embed_extra.1.weight"], sd[p + ".time_embed_extra.1.bias"])
+    h = F.conv1d(x, sd[p + ".in_conv.weight"], sd[p + ".in_conv.bias"], padding=1)
+    cur, i = base, 0
+    for mult in CHANNEL_MULT:
+        for _ in range(DEPTH_MULT):
+            h = res_block(h, sd, f"{p}.blocks.{i}", dict(cin=cur, cout=mult * base, scale=1.0, dil=2), emb)
+            cur = mult * base
+            i += 1
+        h = res_block(h, sd, f"{p}.blocks.{i}", dict(cin=cur, cout=cur, scale=0.5, dil=2), emb)
+        i += 1
+    h = F.gelu(group_norm(h, sd, p + ".out.0.0"))
+    n, c, t = h.shape
+    h = torch.cat([torch.zeros_like(h[..., :1]), h], dim=-1)
+    qkv = F.conv1d(h, sd[p + ".out.1.qkv_proj.weight"], sd[p + ".out.1.qkv_proj.bias"])
+    heads = c // min(c, 64)
+    ch = c // heads
+    q, k, v = qkv.chunk(3, dim=1)
+    scale = 1 / math.sqrt(math.sqrt(ch))
+    w = torch.einsum("bct,bcs->bts", (q * scale).view(n * heads, ch, t + 1), (k * scale).view(n * heads, ch, t + 1))
+    w = torch.softmax(w, dim=-1)
+    a = torch.einsum("bts,bcs->bct", w, v.reshape(n * heads, ch, t + 1)).reshape(n, -1, t + 1)
+    feat = F.conv1d(a, sd[p + ".out.1.c_proj.weight"], sd[p + ".out.1.c_proj.bias"])[..., 0]
+    return F.linear(F.gelu(feat), sd[prefix + "out.1.weight"], sd[prefix + "out.1.bias"])
+
+
+def classifier_cond_fn(sd: State, base: int, labels: Tensor, scale: float = 1.0) -> Callable:
+    """sample_diffusion.py:34-42."""
+
+    def cond_fn(x, ts):
+        with torch.enable_grad():
+            xg = x.detach().clone().requires_grad_()
+            logp = F.log_softmax(classifier(sd, base, xg, ts), dim=-1)
+            grads = torch.autograd.grad(logp[range(len(xg)), labels].sum(), xg)[0]
+        return grads.detach() * scale
+
+    return cond_fn
+
+
 # --------------------------------------------------------------------------
 # VQ (vq.py:98-143, 199-243)
 # --------------------------------------------------------------------------

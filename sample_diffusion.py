@@ -4,8 +4,9 @@ Sample waveforms from a diffusion model on MI355X.  Counterpart of the reference
 (same flags; reference sample_diffusion.py:125-141), running on the gfx950 library: x_T ~ N(0,1), optional
 class labels (uniform or --target-class), `ddpm_sample`, one 16 kHz mono s16 WAV per clip.
 Differences: WAV files are written directly (no ffmpeg); `--schedule` accepts "lambda t: t" / "lambda t: t**P"
-without eval; `--seed`, `--precision` are new; classifier guidance needs the classifier model, which is not
-built yet and is rejected with a clear error.
+without eval; `--seed`, `--precision` are new.  Classifier guidance (`--classifier-path`, reference
+sample_diffusion.py:30-42) evaluates the classifier and its input gradient with stock PyTorch-ROCm autograd
+(first cut) while the UNet and the DDPM step run on the HIP path.
 """
 import argparse
 import math
@@ -15,7 +16,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from vq_voice_swap_amd import DiffusionModel, randn_clips  # noqa: E402
+from vq_voice_swap_amd import Classifier, DiffusionModel, randn_clips  # noqa: E402
 from vq_voice_swap_amd.audio import ChunkWriter, parse_time_schedule  # noqa: E402
 
 
@@ -46,14 +47,19 @@ def sample_labels(args, num_labels, n, device, gen):
     return out.to(dtype=torch.long, device=device)
 
 
-def sample_batch(args, model, device, n, seed, clip_offset, schedule, gen):
+def sample_batch(args, model, classifier, device, n, seed, clip_offset, schedule, gen):
     x_T = randn_clips(n, 64000, device, seed, clip_offset=clip_offset)
-    pred = model.predictor
+    pred, labels = model.predictor, None
     if model.num_labels is not None:
         labels = sample_labels(args, model.num_labels, n, device, gen)
         pred = lambda xs, ts, _l=labels: model.predictor(xs, ts, labels=_l)  # noqa: E731
+    cond_fn = None
+    if classifier is not None:  # reference sample_diffusion.py:34-42, 108-114
+        if labels is None:
+            labels = sample_labels(args, classifier.num_labels, n, device, gen)
+        cond_fn = classifier.guidance_fn(labels, args.classifier_scale)
     return model.diffusion.ddpm_sample(x_T, pred, args.sample_steps, progress=n == 1, constrain=args.constrain,
-                                       schedule=schedule, seed=seed, clip_offset=clip_offset)
+                                       cond_fn=cond_fn, schedule=schedule, seed=seed, clip_offset=clip_offset)
 
 
 def write_clip(path, seq, encoding):
@@ -64,8 +70,6 @@ def write_clip(path, seq, encoding):
 
 def main(argv=None):
     args = arg_parser().parse_args(argv)
-    if args.classifier_path:
-        raise SystemExit("classifier-guided sampling needs the Classifier model (SURVEY.md 8f.1), which this build does not include yet")
     schedule = parse_time_schedule(args.schedule)
     model = DiffusionModel.load(args.checkpoint_path)
     if not torch.cuda.is_available():
@@ -74,15 +78,19 @@ def main(argv=None):
     model.to(device)
     model.eval()
     model.set_precision(args.precision)
+    classifier = None
+    if args.classifier_path:
+        classifier = Classifier.load(args.classifier_path).to(device)
+        classifier.eval()
     seed = args.seed if args.seed is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
     gen = torch.Generator().manual_seed(seed % (2 ** 63))
     if args.num_samples is None:
-        write_clip(args.sample_path, sample_batch(args, model, device, 1, seed, 0, schedule, gen)[0], args.encoding)
+        write_clip(args.sample_path, sample_batch(args, model, classifier, device, 1, seed, 0, schedule, gen)[0], args.encoding)
         return
     os.mkdir(args.sample_path)
     count = 0
     for b in range(int(math.ceil(args.num_samples / args.batch_size))):
-        sample = sample_batch(args, model, device, args.batch_size, seed, b * args.batch_size, schedule, gen)
+        sample = sample_batch(args, model, classifier, device, args.batch_size, seed, b * args.batch_size, schedule, gen)
         for seq in sample:
             if count == args.num_samples:
                 break

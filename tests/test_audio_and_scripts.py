@@ -51,10 +51,11 @@ def test_import_shim_paths():
     sys.path.insert(0, ROOT)
     from vq_voice_swap.dataset import ChunkWriter as W  # noqa: F401
     from vq_voice_swap.diffusion_model import DiffusionModel  # noqa: F401
-    from vq_voice_swap.models import Classifier
+    from vq_voice_swap.models import Classifier, EncoderPredictor
     from vq_voice_swap.vq_vae import VQVAE  # noqa: F401
+    assert Classifier(num_labels=3, base_channels=32).num_labels == 3
     with pytest.raises(NotImplementedError):
-        Classifier(num_labels=3)
+        EncoderPredictor(32, 256, 512)
 
 
 @pytest.mark.gpu

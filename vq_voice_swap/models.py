@@ -15,8 +15,7 @@ class _NotBuilt:
         cls()
 
 
-class Classifier(_NotBuilt):
-    _what = "Classifier (classifier-guided sampling)"
+from vq_voice_swap_amd.classifier import Classifier, ClassifierStem  # noqa: E402,F401
 
 
 class EncoderPredictor(_NotBuilt):

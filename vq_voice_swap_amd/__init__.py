@@ -4,6 +4,7 @@ DiffusionModel / VQVAE API of unixpickle/vq-voice-swap.  See DESIGN.md.
 """
 
 from .base import Savable, atomic_save
+from .classifier import Classifier
 from .diffusion import CosSchedule, Diffusion, ExpSchedule, Schedule, make_schedule, randn_clips
 from .diffusion_model import DiffusionModel
 from .unet import ResBlockModule, UNetEncoder, UNetPredictor
@@ -12,5 +13,5 @@ from .vq_vae import VQVAE
 
 __all__ = [
     "Savable", "atomic_save", "CosSchedule", "Diffusion", "ExpSchedule", "Schedule", "make_schedule", "randn_clips",
-    "DiffusionModel", "ResBlockModule", "UNetEncoder", "UNetPredictor", "VQ", "VQVAE",
+    "DiffusionModel", "Classifier", "ResBlockModule", "UNetEncoder", "UNetPredictor", "VQ", "VQVAE",
 ]

@@ -1,0 +1,143 @@
+"""
+Noised-audio speaker classifier used for classifier-guided sampling (BASELINE config 5).
+
+Parameter layout and semantics follow the reference (`vq_voice_swap/models/classifier.py:18-191`): a stem
+of 27 FiLM ResBlocks (every level ends with a x0.5 block, so 64000 samples become 125 tokens), GroupNorm +
+GELU, an attention pool whose only consumed output is the prepended zero token, GELU and a linear head.
+
+FIRST CUT: guidance needs the gradient of log p(y | x_t) with respect to x_t, i.e.
+a backward pass through the whole classifier.  The library has no backward kernels yet, so this module
+evaluates the classifier with stock PyTorch-ROCm ops and autograd on the GPU, while the UNet predictor and
+the DDPM step keep running on the hand-written HIP path.  It is *not* part of the accelerated hot path and
+nothing in `unet.py` / `diffusion.py` / `vq.py` falls back to it.
+"""
+
+from __future__ import annotations
+
+import math
+from typing import Any, Dict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .base import Savable
+from .unet import CHANNEL_MULT, ResBlock, _groups, _scaled, _seq
+
+
+def _gn(x: torch.Tensor, gn: nn.GroupNorm) -> torch.Tensor:
+    return F.group_norm(x, gn.num_groups, gn.weight, gn.bias, gn.eps)
+
+
+def resblock_autograd(block: ResBlock, x: torch.Tensor, emb: torch.Tensor) -> torch.Tensor:
+    """Differentiable evaluation of one residual block from its parameter container."""
+    down = block.scale_factor < 1.0
+    up = block.scale_factor > 1.0
+
+    def resize(t):
+        if down:
+            return F.avg_pool1d(t, 2)
+        if up:
+            return F.interpolate(t, scale_factor=2.0)
+        return t
+
+    h = F.gelu(_gn(x, block.pre_cond[0][0]))
+    h = block.pre_cond[2](resize(h))
+    h = _gn(h, block.pre_cond[3])
+    if block.emb_channels:
+        ab = block.cond_layers[1](F.gelu(emb))[..., None]
+        a, b = ab[:, : block.out_channels], ab[:, block.out_channels:]
+        h = h * (a + 1) + b
+    h = block.post_cond[len(block.post_cond) - 1](F.gelu(h))
+    s = resize(x)
+    if isinstance(block.skip[1], nn.Conv1d):
+        s = block.skip[1](s)
+    return s + h
+
+
+class AttentionPool1d(nn.Module):
+    def __init__(self, channels: int, head_channels: int = 64, out_channels: int = None):
+        super().__init__()
+        assert channels % head_channels == 0
+        self.qkv_proj = nn.Conv1d(channels, 3 * channels, 1)
+        self.c_proj = nn.Conv1d(channels, out_channels or channels, 1)
+        self.num_heads = channels // head_channels
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        n, c, t = x.shape
+        x = torch.cat([x.new_zeros(n, c, 1), x], dim=-1)          # query token 0 is all zeros (classifier.py:154)
+        q, k, v = self.qkv_proj(x).chunk(3, dim=1)
+        ch = c // self.num_heads
+        s = ch ** -0.25                                              # both q and k are scaled (classifier.py:181-186)
+        q = (q * s).reshape(n * self.num_heads, ch, t + 1)
+        k = (k * s).reshape(n * self.num_heads, ch, t + 1)
+        v = v.reshape(n * self.num_heads, ch, t + 1)
+        w = torch.softmax(torch.einsum("bct,bcs->bts", q, k), dim=-1)
+        a = torch.einsum("bts,bcs->bct", w, v).reshape(n, c, t + 1)
+        return self.c_proj(a)[..., 0]
+
+
+class ClassifierStem(nn.Module):
+    def __init__(self, base_channels: int = 32, channel_mult=CHANNEL_MULT, output_mult: int = 16, depth_mult: int = 2):
+        super().__init__()
+        self.base_channels, self.channel_mult = base_channels, tuple(channel_mult)
+        self.output_mult, self.depth_mult = output_mult, depth_mult
+        self.out_channels = base_channels * output_mult
+        E = self.embed_dim = 4 * base_channels
+        self.time_embed = nn.Module()
+        self.time_embed.proj = nn.Linear(E, E)
+        self.time_embed_extra = _seq(None, nn.Linear(E, E))
+        self.in_conv = nn.Conv1d(1, base_channels, 3, padding=1)
+        blocks, cur = [], base_channels
+        for mult in self.channel_mult:
+            for _ in range(depth_mult):
+                blocks.append(ResBlock(cur, E, mult * base_channels))
+                cur = mult * base_channels
+            blocks.append(ResBlock(cur, E, cur, scale_factor=0.5))
+        self.blocks = nn.ModuleList(blocks)
+        self.out = _seq(_seq(nn.GroupNorm(_groups(cur), cur), None),
+                        AttentionPool1d(cur, head_channels=min(cur, 64), out_channels=self.out_channels))
+
+    def conditional_embedding(self, ts: torch.Tensor) -> torch.Tensor:
+        E = self.embed_dim
+        half = E // 2
+        freqs = (torch.exp(-math.log(100.0 / 0.1) * torch.arange(0, half, dtype=torch.float32) / (half - 1)) * 100.0).to(ts)
+        args = ts[:, None] * freqs[None]
+        e = self.time_embed.proj(torch.cat([torch.cos(args), torch.sin(args)], dim=-1))
+        return self.time_embed_extra[1](F.gelu(e))
+
+    def forward(self, x: torch.Tensor, ts: torch.Tensor, use_checkpoint: bool = False) -> torch.Tensor:
+        emb = self.conditional_embedding(ts)
+        h = self.in_conv(x)
+        for block in self.blocks:
+            h = resblock_autograd(block, h, emb)
+        h = F.gelu(_gn(h, self.out[0][0]))
+        return self.out[1](h)
+
+
+class Classifier(Savable):
+    def __init__(self, num_labels: int, **kwargs):
+        super().__init__()
+        self.num_labels = num_labels
+        self.stem = ClassifierStem(**kwargs)
+        self.out = _seq(None, _scaled(nn.Linear(self.stem.out_channels, num_labels), 0.0))
+
+    def forward(self, x: torch.Tensor, ts: torch.Tensor, use_checkpoint: bool = False) -> torch.Tensor:
+        return self.out[1](F.gelu(self.stem(x, ts)))
+
+    def save_kwargs(self) -> Dict[str, Any]:
+        s = self.stem
+        return dict(num_labels=self.num_labels, base_channels=s.base_channels, channel_mult=s.channel_mult,
+                    output_mult=s.output_mult, depth_mult=s.depth_mult)
+
+    def guidance_fn(self, labels: torch.Tensor, scale: float = 1.0):
+        """cond_fn(x, ts) = scale * d/dx log softmax(classifier(x, ts))[labels]   (sample_diffusion.py:34-42)"""
+
+        def cond_fn(x, ts):
+            with torch.enable_grad():
+                xg = x.detach().clone().requires_grad_()
+                logp = F.log_softmax(self(xg, ts), dim=-1)
+                grads = torch.autograd.grad(logp[range(len(xg)), labels].sum(), xg)[0]
+            return grads.detach() * scale
+
+        return cond_fn
