@@ -445,6 +445,10 @@ int launch_p(const ConvArgs& a, int B, hipStream_t st, bool wide, bool big_halo,
       return big_halo ? launch_t<T, X3, 2, 64, false, 2>(a, B, st) : launch_t<T, X3, 2, 4, false, 2>(a, B, st);
     }
   }
+  if constexpr (X3) {
+    // fp32 mode stages two bf16 planes, so LDS allows one workgroup per CU: make it 8 waves (4 x 64 rows, 2 x 32 channels)
+    if (wide) return big_halo ? launch_t<T, X3, 1, 64, false, 2>(a, B, st) : launch_t<T, X3, 1, 4, false, 2>(a, B, st);
+  }
   if (a.skip != nullptr && !X3) {
     if (wide) return big_halo ? launch_t<T, X3, 2, 64, true>(a, B, st) : launch_t<T, X3, 2, 4, true>(a, B, st);
     return big_halo ? launch_t<T, X3, 1, 64, true>(a, B, st) : launch_t<T, X3, 1, 4, true>(a, B, st);
