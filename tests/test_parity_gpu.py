@@ -278,3 +278,24 @@ def test_resblock_config_sweep_vs_oracle(dev, prec, tol):
         want = ref_cpu.res_block(x, sd, "b", dict(cin=cin, cout=cout, scale=scale, dil=dil), e)
         got = m(x.to(dev), None if e is None else e.to(dev)).cpu()
         assert got.shape == want.shape and rel_rms(got, want) < tol, (i, cin, cout, scale, dil, L, B, rel_rms(got, want))
+
+
+def test_handle_lifecycle_and_small_shapes(dev):
+    """The device handle is rebuilt when batch / length grow or precision changes; tiny shapes work; memory is returned."""
+    model = det_model(DiffusionModel("unet", 32))
+    sd = {"predictor." + k: v.detach() for k, v in model.predictor.state_dict().items()}
+    free0 = torch.cuda.mem_get_info()[0]
+    for B, T in ((1, 256), (3, 512), (2, 256), (5, 1024)):
+        x, ts = seeded((B, 1, T), 10 * B + T), torch.linspace(0.1, 0.9, B)
+        want = ref_cpu.unet_predictor(sd, 32, x, ts)
+        got = model.predictor(x.to(dev), ts.to(dev)).cpu()
+        assert rel_rms(got, want) < FP32_REL, (B, T)
+    h = model.predictor._handle
+    assert h.cfg.max_batch >= 5 and h.cfg.max_T >= 1024 and h.kernel_count() > 250
+    assert h.model_bytes(2, 1024) == 2 * h.model_bytes(1, 1024) and h.flops(1, 2048) == 2 * h.flops(1, 1024)
+    model.set_precision("bf16")
+    assert model.predictor._handle is None
+    model.predictor(seeded((1, 1, 256), 1).to(dev), torch.tensor([0.5], device=dev))
+    model.predictor.invalidate()
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20), "device memory of destroyed handles was not returned"
