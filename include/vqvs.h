@@ -39,6 +39,7 @@ extern "C" {
 #define VQVS_KIND_PREDICTOR 0 /* UNetPredictor  (reference vq_voice_swap/models/unet.py:16-184) */
 #define VQVS_KIND_ENCODER 1   /* UNetEncoder    (reference unet.py:187-245) */
 #define VQVS_KIND_RESBLOCK 2  /* one ResBlock   (reference unet.py:248-316); unit-test granularity */
+#define VQVS_KIND_CLASSIFIER 3 /* Classifier   (reference vq_voice_swap/models/classifier.py:18-191), base_channels + num_labels */
 
 /* activation storage / arithmetic */
 #define VQVS_PREC_F32 0  /* fp32 activations; convs as 3-term bf16-split MFMA, fp32 accumulate (~2^-17 rel.) */
@@ -96,6 +97,19 @@ int vqvs_encoder_forward(vqvs_model* m, const float* d_x, float* d_z, int B, int
 /* y = ResBlock.forward(x, emb)   reference unet.py:307-316 (VQVS_KIND_RESBLOCK handles)
  *   d_x [B,rb_cin,L] f32, d_emb [B,rb_emb_channels] f32 or NULL -> d_y [B,rb_cout,L'] f32 */
 int vqvs_resblock_forward(vqvs_model* m, const float* d_x, const float* d_emb, float* d_y, int B, int L, void* stream);
+
+/* ---- classifier guidance (BASELINE config 5) -------------------------------------
+ * logits = Classifier.forward(x, ts)   reference models/classifier.py:31-36 (stem :111-121, attention pool
+ * :153-191).  VQVS_KIND_CLASSIFIER handles; parameters are named relative to the Classifier module
+ * ("stem.blocks.3.pre_cond.2.weight", "out.1.weight", ...).  T must be a multiple of 512.
+ *   d_x [B,1,T] f32, d_ts [B] f32 -> d_logits [B,num_labels] f32 */
+int vqvs_classifier_forward(vqvs_model* m, const float* d_x, const float* d_ts, float* d_logits, int B, int T, void* stream);
+/* grad = scale * d/dx log_softmax(Classifier(x, ts))[labels]   -- what the reference's cond_fn obtains with
+ * torch.autograd.grad (sample_diffusion.py:34-42).  Runs the forward pass, then an explicit input-gradient
+ * schedule (transposed convolutions on the MFMA kernel, GroupNorm / GELU / attention-pool backward).
+ *   d_labels [B] int64, d_grad [B,1,T] f32 out, d_logits [B,num_labels] f32 out or NULL */
+int vqvs_classifier_guidance(vqvs_model* m, const float* d_x, const float* d_ts, const int64_t* d_labels, float scale,
+                             float* d_grad, float* d_logits, int B, int T, void* stream);
 
 /* ---- DDPM reverse step --------------------------------------------------------
  * x_prev = Diffusion.ddpm_previous(x_t, ts, step, eps, noise, sigma_large, constrain)

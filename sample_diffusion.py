@@ -5,8 +5,8 @@ Sample waveforms from a diffusion model on MI355X.  Counterpart of the reference
 class labels (uniform or --target-class), `ddpm_sample`, one 16 kHz mono s16 WAV per clip.
 Differences: WAV files are written directly (no ffmpeg); `--schedule` accepts "lambda t: t" / "lambda t: t**P"
 without eval; `--seed`, `--precision` are new.  Classifier guidance (`--classifier-path`, reference
-sample_diffusion.py:30-42) evaluates the classifier and its input gradient with stock PyTorch-ROCm autograd
-(first cut) while the UNet and the DDPM step run on the HIP path.
+sample_diffusion.py:30-42) runs on the same library: the classifier forward and the gradient of log p(y | x_t)
+are `vqvs_classifier_guidance` (explicit HIP backward schedule, no autograd).
 """
 import argparse
 import math
@@ -82,6 +82,7 @@ def main(argv=None):
     if args.classifier_path:
         classifier = Classifier.load(args.classifier_path).to(device)
         classifier.eval()
+        classifier.set_precision(args.precision)
     seed = args.seed if args.seed is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
     gen = torch.Generator().manual_seed(seed % (2 ** 63))
     if args.num_samples is None:

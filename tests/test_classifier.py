@@ -1,5 +1,5 @@
-"""Classifier guidance (BASELINE config 5, scope row G1 / 8f.1 first cut): parameter layout, logits and input
-gradient against the golden vectors of the reference; guided DDPM steps through the HIP path against the oracle."""
+"""Classifier guidance (BASELINE config 5, scope row G1 / 8f.1): parameter layout against the golden vectors of the
+reference (CPU); native logits, native input gradient and guided DDPM sampling against the oracle (GPU)."""
 import numpy as np
 import pytest
 import torch
@@ -30,13 +30,59 @@ def test_classifier_matches_reference_golden(golden):
     # oracle pinned by the reference's outputs
     assert torch.equal(ref_cpu.classifier(sd, 32, x, ts), torch.from_numpy(z["logits"]))
     assert torch.equal(ref_cpu.classifier_cond_fn(sd, 32, labels)(x, ts), torch.from_numpy(z["grad"]))
-    # the module itself (stock torch ops) reproduces them too
+    # the parameter containers evaluated with stock torch ops reproduce them too (layout check)
     xg = x.clone().requires_grad_()
-    logits = clf(xg, ts)
+    logits = clf.forward_torch(xg, ts)
     assert (logits.detach() - torch.from_numpy(z["logits"])).abs().max().item() <= 1e-6
     g = torch.autograd.grad(F.log_softmax(logits, dim=-1)[range(2), labels].sum(), xg)[0]
     assert rel_rms(g, torch.from_numpy(z["grad"])) < 1e-5
-    assert rel_rms(clf.guidance_fn(labels, 2.0)(x, ts), 2.0 * torch.from_numpy(z["grad"])) < 1e-5
+    # the sampling-path entry points have no CPU fallback
+    with pytest.raises(RuntimeError):
+        clf(x, ts)
+    with pytest.raises(RuntimeError):
+        clf.guidance_fn(labels, 2.0)(x, ts)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,tol_logit,tol_grad", [("fp32", 2e-4, 2e-3), ("bf16", 5e-2, 1.5e-1)])
+def test_native_classifier_vs_golden(golden, precision, tol_logit, tol_grad):
+    """logits and d log p(y|x)/dx of the HIP path against the reference's own outputs (fixture F9)."""
+    z = golden("f9_classifier32")
+    dev = torch.device("cuda:0")
+    clf = make_classifier().to(dev)
+    clf.set_precision(precision)
+    x = seeded((2, 1, 64000), int(z["x_seed"])).to(dev)
+    ts, labels = torch.from_numpy(z["ts"]).to(dev), torch.from_numpy(z["labels"]).to(dev)
+    want_logits, want_grad = torch.from_numpy(z["logits"]), torch.from_numpy(z["grad"])
+    logits = clf(x, ts).cpu()
+    assert rel_rms(logits, want_logits) < tol_logit
+    grad, logits2 = clf.log_prob_grad(x, ts, labels, 1.0, return_logits=True)
+    assert torch.equal(logits2.cpu(), logits)
+    assert rel_rms(grad.cpu(), want_grad) < tol_grad
+    # linear in the scale, deterministic
+    g3 = clf.guidance_fn(labels, 3.0)(x, ts)
+    assert rel_rms(g3.cpu(), 3.0 * grad.cpu()) < (1e-4 if precision == "fp32" else 2e-2)  # 3x changes the operand rounding
+    assert torch.equal(clf.log_prob_grad(x, ts, labels, 1.0), grad)
+
+
+@pytest.mark.gpu
+def test_native_classifier_shapes_and_errors():
+    dev = torch.device("cuda:0")
+    clf = make_classifier().to(dev)
+    sd = {k: v.detach().cpu() for k, v in clf.state_dict().items()}
+    # a short ragged batch: 3 clips of 1536 samples (3 tokens), per-clip timesteps
+    x = seeded((3, 1, 1536), 5)
+    ts = torch.tensor([0.1, 0.5, 0.95])
+    labels = torch.tensor([0, 6, 2])
+    want = ref_cpu.classifier(sd, 32, x, ts)
+    want_g = ref_cpu.classifier_cond_fn(sd, 32, labels, 1.0)(x, ts)
+    got_g, got = clf.log_prob_grad(x.to(dev), ts.to(dev), labels.to(dev), 1.0, return_logits=True)
+    assert rel_rms(got.cpu(), want) < 2e-4
+    assert rel_rms(got_g.cpu(), want_g) < 2e-3
+    with pytest.raises(ValueError):
+        clf(torch.zeros(1, 1, 1000, device=dev), torch.zeros(1, device=dev))
+    with pytest.raises(ValueError):
+        clf.log_prob_grad(x.to(dev), ts.to(dev), labels[:2].to(dev))
 
 
 def test_classifier_checkpoint_roundtrip(tmp_path):

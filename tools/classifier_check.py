@@ -1,0 +1,39 @@
+"""Parity numbers and timing of the native classifier (forward and guidance gradient) on the GPU."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+import torch
+from vq_voice_swap_amd import Classifier
+from vq_voice_swap_amd.det_init import det_init_
+from util import rel_rms, seeded
+
+dev = torch.device("cuda:0")
+z = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "f9_classifier32.npz"))
+clf = Classifier(num_labels=7, base_channels=32)
+det_init_(clf.state_dict().items())
+clf.eval().to(dev)
+x = seeded((2, 1, 64000), int(z["x_seed"])).to(dev)
+ts, labels = torch.from_numpy(z["ts"]).to(dev), torch.from_numpy(z["labels"]).to(dev)
+for prec in ("fp32", "bf16"):
+    clf.set_precision(prec)
+    g, lg = clf.log_prob_grad(x, ts, labels, 1.0, return_logits=True)
+    print(prec, "logits rel", rel_rms(lg.cpu(), torch.from_numpy(z["logits"])), "grad rel", rel_rms(g.cpu(), torch.from_numpy(z["grad"])))
+for base, B in ((32, 32), (32, 64), (64, 32)):
+    clf = Classifier(num_labels=251, base_channels=base)
+    det_init_(clf.state_dict().items())
+    clf.eval().to(dev)
+    xb = torch.randn(B, 1, 64000, device=dev)
+    tb = torch.rand(B, device=dev)
+    lb = torch.randint(0, 251, (B,), device=dev)
+    for prec in ("bf16", "fp32"):
+        clf.set_precision(prec)
+        for fn, name in ((lambda: clf(xb, tb), "forward"), (lambda: clf.log_prob_grad(xb, tb, lb), "guidance")):
+            fn(); torch.cuda.synchronize()
+            t0 = time.time()
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            print(f"classifier{base} B={B} {prec} {name}: {(time.time() - t0) / 5 * 1e3:.2f} ms", flush=True)
+        h = clf.handle(dev, B, 64000)
+        print("   device bytes %.2f GB, kernels %d" % (h.device_bytes() / 1e9, h.kernel_count()))

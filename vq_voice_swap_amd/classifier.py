@@ -1,15 +1,19 @@
 """
-Noised-audio speaker classifier used for classifier-guided sampling (BASELINE config 5).
+Noised-audio speaker classifier used for classifier-guided sampling (BASELINE config 5, SURVEY.md 8a row G1).
 
 Parameter layout and semantics follow the reference (`vq_voice_swap/models/classifier.py:18-191`): a stem
 of 27 FiLM ResBlocks (every level ends with a x0.5 block, so 64000 samples become 125 tokens), GroupNorm +
 GELU, an attention pool whose only consumed output is the prepended zero token, GELU and a linear head.
 
-FIRST CUT: guidance needs the gradient of log p(y | x_t) with respect to x_t, i.e.
-a backward pass through the whole classifier.  The library has no backward kernels yet, so this module
-evaluates the classifier with stock PyTorch-ROCm ops and autograd on the GPU, while the UNet predictor and
-the DDPM step keep running on the hand-written HIP path.  It is *not* part of the accelerated hot path and
-nothing in `unet.py` / `diffusion.py` / `vq.py` falls back to it.
+`Classifier.forward` and `Classifier.guidance_fn` run on the gfx950 library (`vqvs_classifier_forward`,
+`vqvs_classifier_guidance`): the forward pass reuses the fused ResBlock schedule of the UNets, and the gradient
+of log p(y | x_t) with respect to x_t -- which the reference obtains with `torch.autograd.grad`
+(`sample_diffusion.py:34-42`) -- is an explicit backward schedule (transposed convolutions on the MFMA kernel,
+GroupNorm / GELU / avg-pool / attention-pool backward kernels).  There is no CPU path: CPU tensors raise.
+
+`forward_torch` evaluates the same module with stock differentiable PyTorch ops.  It exists for the CPU tests
+that pin the parameter layout against the reference's golden vectors and for training-side code; nothing on
+the sampling path calls it.
 """
 
 from __future__ import annotations
@@ -22,7 +26,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .base import Savable
-from .unet import CHANNEL_MULT, ResBlock, _groups, _scaled, _seq
+from . import _native
+from .unet import CHANNEL_MULT, ResBlock, _NativeModule, _groups, _scaled, _seq
 
 
 def _gn(x: torch.Tensor, gn: nn.GroupNorm) -> torch.Tensor:
@@ -115,29 +120,78 @@ class ClassifierStem(nn.Module):
         return self.out[1](h)
 
 
-class Classifier(Savable):
+class Classifier(_NativeModule, Savable):
     def __init__(self, num_labels: int, **kwargs):
         super().__init__()
         self.num_labels = num_labels
         self.stem = ClassifierStem(**kwargs)
+        if tuple(self.stem.channel_mult) != CHANNEL_MULT or self.stem.depth_mult != 2 or self.stem.output_mult != 16:
+            raise ValueError("the gfx950 library implements the reference's default classifier topology only")
         self.out = _seq(None, _scaled(nn.Linear(self.stem.out_channels, num_labels), 0.0))
-
-    def forward(self, x: torch.Tensor, ts: torch.Tensor, use_checkpoint: bool = False) -> torch.Tensor:
-        return self.out[1](F.gelu(self.stem(x, ts)))
 
     def save_kwargs(self) -> Dict[str, Any]:
         s = self.stem
         return dict(num_labels=self.num_labels, base_channels=s.base_channels, channel_mult=s.channel_mult,
                     output_mult=s.output_mult, depth_mult=s.depth_mult)
 
+    @property
+    def downsample_rate(self) -> int:
+        return 2 ** len(self.stem.channel_mult)
+
+    def _cfg(self) -> _native.Cfg:
+        cfg = _native.Cfg()
+        cfg.kind = _native.KIND_CLASSIFIER
+        cfg.base_channels = self.stem.base_channels
+        cfg.in_channels = 1
+        cfg.num_labels = self.num_labels
+        return cfg
+
+    def _prepare(self, x: torch.Tensor, ts: torch.Tensor):
+        _native.require_cuda(x, ts)
+        if x.dim() != 3 or x.shape[1] != 1:
+            raise ValueError(f"expected x of shape [N, 1, T], got {tuple(x.shape)}")
+        B, _, T = x.shape
+        if T % self.downsample_rate:
+            raise ValueError(f"T={T} is not a multiple of the classifier downsample rate {self.downsample_rate}")
+        x = x.detach().to(torch.float32).contiguous()
+        ts = ts.detach().to(device=x.device, dtype=torch.float32).contiguous()
+        if ts.shape != (B,):
+            raise ValueError(f"expected ts of shape [{B}], got {tuple(ts.shape)}")
+        return x, ts, B, T
+
+    def forward(self, x: torch.Tensor, ts: torch.Tensor, use_checkpoint: bool = False, **kwargs) -> torch.Tensor:
+        """logits [N, num_labels] (classifier.py:31-36) through `vqvs_classifier_forward`."""
+        x, ts, B, T = self._prepare(x, ts)
+        h = self.handle(x.device, B, T)
+        logits = torch.empty(B, self.num_labels, device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _native.check(_native.lib().vqvs_classifier_forward(h.ptr, x.data_ptr(), ts.data_ptr(), logits.data_ptr(), B, T,
+                                                               _native._stream_ptr()))
+        return logits
+
+    def log_prob_grad(self, x: torch.Tensor, ts: torch.Tensor, labels: torch.Tensor, scale: float = 1.0, return_logits: bool = False):
+        """scale * d/dx log_softmax(self(x, ts))[labels] through `vqvs_classifier_guidance` (forward + explicit backward)."""
+        x, ts, B, T = self._prepare(x, ts)
+        _native.require_cuda(labels)
+        labels = labels.detach().to(device=x.device, dtype=torch.int64).contiguous()
+        if labels.shape != (B,):
+            raise ValueError(f"expected labels of shape [{B}], got {tuple(labels.shape)}")
+        h = self.handle(x.device, B, T)
+        grad = torch.empty_like(x)
+        logits = torch.empty(B, self.num_labels, device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _native.check(_native.lib().vqvs_classifier_guidance(h.ptr, x.data_ptr(), ts.data_ptr(), labels.data_ptr(), float(scale),
+                                                                grad.data_ptr(), logits.data_ptr(), B, T, _native._stream_ptr()))
+        return (grad, logits) if return_logits else grad
+
     def guidance_fn(self, labels: torch.Tensor, scale: float = 1.0):
         """cond_fn(x, ts) = scale * d/dx log softmax(classifier(x, ts))[labels]   (sample_diffusion.py:34-42)"""
 
         def cond_fn(x, ts):
-            with torch.enable_grad():
-                xg = x.detach().clone().requires_grad_()
-                logp = F.log_softmax(self(xg, ts), dim=-1)
-                grads = torch.autograd.grad(logp[range(len(xg)), labels].sum(), xg)[0]
-            return grads.detach() * scale
+            return self.log_prob_grad(x, ts, labels.to(x.device), scale)
 
         return cond_fn
+
+    def forward_torch(self, x: torch.Tensor, ts: torch.Tensor) -> torch.Tensor:
+        """The same function with stock differentiable PyTorch ops (tests / training-side code only)."""
+        return self.out[1](F.gelu(self.stem(x, ts)))

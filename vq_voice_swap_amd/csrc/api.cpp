@@ -106,6 +106,7 @@ static int check_run(vqvs_model* m, int kind, int B, int L) {
   if (m->cfg.kind != kind) VQVS_FAIL(VQVS_ERR_STATE, "handle kind %d used as kind %d", m->cfg.kind, kind);
   if (B < 1 || B > m->cfg.max_batch) VQVS_FAIL(VQVS_ERR_ARG, "batch %d outside 1..%d", B, m->cfg.max_batch);
   if (L < 1 || L > m->cfg.max_T) VQVS_FAIL(VQVS_ERR_ARG, "length %d outside 1..%d", L, m->cfg.max_T);
+  if (kind == VQVS_KIND_CLASSIFIER && (L % 512)) VQVS_FAIL(VQVS_ERR_ARG, "T=%d is not a multiple of the classifier downsample rate 512", L);
   if (kind != VQVS_KIND_RESBLOCK && (L % 256)) VQVS_FAIL(VQVS_ERR_ARG, "T=%d is not a multiple of the UNet downsample rate 256", L);
   if (kind == VQVS_KIND_RESBLOCK && m->cfg.rb_resize == RESIZE_AVG2 && (L % 2)) VQVS_FAIL(VQVS_ERR_ARG, "avg-pool resblock needs even L");
   return 0;
@@ -152,6 +153,43 @@ int vqvs_resblock_forward(vqvs_model* m, const float* d_x, const float* d_emb, f
   c.x = d_x;
   c.emb = d_emb;
   c.out = d_y;
+  c.st = reinterpret_cast<hipStream_t>(stream);
+  return run_model(m, c);
+}
+
+int vqvs_classifier_forward(vqvs_model* m, const float* d_x, const float* d_ts, float* d_logits, int B, int T, void* stream) {
+  if (int e = check_run(m, VQVS_KIND_CLASSIFIER, B, T)) return e;
+  if (!d_x || !d_ts || !d_logits) VQVS_FAIL(VQVS_ERR_ARG, "x, ts and logits must be non-NULL");
+  RunCtx c;
+  c.B = B;
+  c.Lbase = T;
+  c.x = d_x;
+  c.ts = d_ts;
+  c.out = d_logits;
+  c.st = reinterpret_cast<hipStream_t>(stream);
+  return run_model(m, c);
+}
+
+int vqvs_classifier_guidance(vqvs_model* m, const float* d_x, const float* d_ts, const int64_t* d_labels, float scale, float* d_grad,
+                             float* d_logits, int B, int T, void* stream) {
+  if (int e = check_run(m, VQVS_KIND_CLASSIFIER, B, T)) return e;
+  if (!d_x || !d_ts || !d_labels || !d_grad) VQVS_FAIL(VQVS_ERR_ARG, "x, ts, labels and grad must be non-NULL");
+  float* logits = d_logits;
+  if (!logits) {
+    void* scratch = nullptr;
+    if (int e = scratch_get((size_t)B * m->cfg.num_labels * 4, &scratch)) return e;
+    logits = reinterpret_cast<float*>(scratch);
+  }
+  RunCtx c;
+  c.B = B;
+  c.Lbase = T;
+  c.x = d_x;
+  c.ts = d_ts;
+  c.labels = d_labels;
+  c.out = logits;
+  c.backward = true;
+  c.gscale = scale;
+  c.grad_out = d_grad;
   c.st = reinterpret_cast<hipStream_t>(stream);
   return run_model(m, c);
 }

@@ -56,6 +56,24 @@ __device__ __forceinline__ float gelu_f(float v) {
   return 0.5f * v * (1.0f + copysignf(e, v));
 }
 
+// d/dv gelu(v) = Phi(v) + v*phi(v), same erf evaluation as gelu_f (backward of the classifier, guidance)
+__device__ __forceinline__ float gelu_grad_f(float v) {
+  const float z = fabsf(v) * 0.70710678118654752440f;
+  float p = fmaf(0.0000430638f, z, 0.0002765672f);
+  p = fmaf(p, z, 0.0001520143f);
+  p = fmaf(p, z, 0.0092705272f);
+  p = fmaf(p, z, 0.0422820123f);
+  p = fmaf(p, z, 0.0705230784f);
+  p = fmaf(p, z, 1.0f);
+  p = p * p;
+  p = p * p;
+  p = p * p;
+  p = p * p;
+  const float e = 1.0f - __builtin_amdgcn_rcpf(p);
+  const float Phi = 0.5f * (1.0f + copysignf(e, v));
+  return fmaf(v * 0.39894228040143267794f, __expf(-0.5f * v * v), Phi);
+}
+
 // Packed-math variants (v_pk_fma_f32 / v_pk_mul_f32 process two floats per lane per issue; a plain
 // wave64 VALU instruction occupies the SIMD for 4 cycles on gfx950, so the prologue is written on
 // float2 throughout).

@@ -105,6 +105,7 @@ struct GnArgs {  // per-(clip,channel) scale/shift of GroupNorm [+FiLM]; nn.Grou
   const float* film;   // [B][film_stride] rows (a | b) at film_off, or nullptr   (unet.py:311-314)
   int film_stride, film_off;
   float2* ss;          // out [B][Ctot]
+  float2* mr;          // optional out [B][Ctot]: (mean, rstd) of the channel's group (kept for the backward pass)
 };
 int launch_gn_prepare(const GnArgs& a, int B, hipStream_t st);
 
@@ -139,6 +140,76 @@ struct XformArgs {  // g = gelu(x*scale + shift) [+ avg_pool1d(.,2)], written on
   int C, Lin, Lout, avg, ss_stride, ss_c0;
 };
 int launch_xform(const XformArgs& a, int B, int precision, hipStream_t st);
+
+// ----------------------------------------------------------------------------------
+// Input-gradient kernels of the noised-audio classifier (guidance, reference sample_diffusion.py:34-42):
+// the backward pass of ResBlock (unet.py:307-316) with respect to its input only (no weight gradients).
+// The two transposed convolutions of a block run on the forward MFMA kernel with transposed, tap-flipped
+// weights; the kernels below are the element-wise pieces in between.
+// ----------------------------------------------------------------------------------
+struct BwActArgs {  // du = resize^T(t) * gelu'(u), u = xf*scale + shift;  partial sums (sum du, sum du*u) per tile
+  const void* t;     // gradient w.r.t. the activation output: [B][L][C], or [B][L/2][C] when up (avg-pool backward)
+  const void* xf;    // forward tensor the GroupNorm read: [B][L][C]
+  const float2* ss;  // [B][C] forward (scale, shift)
+  void* du;          // out [B][L][C] (may alias t when !up)
+  float* partials;   // [B][ntiles][C][2], tiles of STAT_TILE rows
+  int C, L, up;
+};
+int launch_bw_act(const BwActArgs& a, int B, int precision, hipStream_t st);
+
+struct GnBwArgs {  // GroupNorm backward coefficients: dx = P*du + Q*x + R  per (clip, channel)
+  const float* partials;  // [B][ntiles][C][2] from bw_act
+  int ntiles, C, groups;
+  double inv_count;       // 1 / (channels_per_group * L)
+  const float2* ss;       // forward (scale, shift) = (rstd*gamma', beta' - mean*rstd*gamma')
+  const float2* mr;       // forward (mean, rstd)
+  float4* coef;           // out [B][C] (P, Q, R, 0)
+};
+int launch_gn_bw(const GnBwArgs& a, int B, hipStream_t st);
+
+struct BwAffineArgs {  // out = P*du + Q*xf + R (+ skip gradient) (+ extra)
+  const void* du;
+  const void* xf;
+  const float4* coef;
+  const void* skip;   // gradient arriving over the identity skip, or nullptr
+  int skip_half;      // 1: skip is [B][L/2][C] and enters as 0.5*skip[t>>1] (avg-pool backward)
+  const void* extra;  // second same-shape addend (gradient through the 1x1 skip convolution), or nullptr
+  void* out;          // [B][L][C] (may alias du)
+  int C, L;
+};
+int launch_bw_affine(const BwAffineArgs& a, int B, int precision, hipStream_t st);
+
+struct InConvBwArgs {  // dx[b][t] = sum_k sum_c w[c][k] * dh[b][t-k+1][c]   (backward of unet.py:137 in_conv, Cin = 1)
+  const void* dh;   // [B][T][C]
+  const float* w;   // [C][3]
+  float* out;       // [B][T] f32
+  int C, T;
+};
+int launch_in_conv_bw(const InConvBwArgs& a, int B, int precision, hipStream_t st);
+
+// Classifier head (classifier.py:98-104, 153-191, 26-28): GroupNorm+GELU, attention pool whose only consumed output
+// is the prepended zero token, c_proj, GELU, Linear -- and, when labels are given, the gradient of
+// gscale * log_softmax(logits)[label] with respect to the head's input.  One workgroup per clip.
+struct HeadArgs {
+  const void* h;       // [B][L][C] output of the last block
+  const float2* ss;    // [B][C] GroupNorm (scale, shift) of stem.out.0.0
+  const float2* mr;    // [B][C] (mean, rstd)
+  int C, L, heads, F, NL, groups;
+  double inv_count;
+  const float* r;      // [heads][C]  ch^-1/2 * Wk_h^T bq_h   (query token is constant: its input is zero)
+  const float* c0;     // [heads]     ch^-1/2 * bq_h . bk_h
+  const float* wv;     // [C][C] value rows of qkv_proj
+  const float* bv;     // [C]
+  const float* wc;     // [F][C] c_proj
+  const float* bc;     // [F]
+  const float* wl;     // [NL][F] out.1
+  const float* bl;     // [NL]
+  float* logits;       // [B][NL] out
+  const int64_t* labels;  // [B] or nullptr = forward only
+  float gscale;
+  void* dh;            // [B][L][C] out (gradient), when labels
+};
+int launch_cls_head(const HeadArgs& a, int B, int precision, hipStream_t st);
 
 // layout changes at the library boundary (reference tensors are NCT float32)
 int launch_nct_to_ntc(const float* in, void* out, float* stats, int B, int C, int L, int ntiles, int precision, hipStream_t st);

@@ -208,6 +208,7 @@ __global__ __launch_bounds__(256) void gn_prepare_kernel(const GnArgs a) {
       shift = shift * fa + fb;
     }
     a.ss[(size_t)b * a.Ctot + c] = make_float2((float)scale, (float)shift);
+    if (a.mr) a.mr[(size_t)b * a.Ctot + c] = make_float2((float)gmean[g], (float)grstd[g]);
   }
 }
 

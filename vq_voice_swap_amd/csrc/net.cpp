@@ -69,6 +69,19 @@ void encoder_blocks(int base, std::vector<BlockSpec>& blocks) {
   }
 }
 
+// ClassifierStem (classifier.py:79-96): like the encoder, but FiLM-conditioned and with a x0.5 block after EVERY level
+void classifier_blocks(int base, std::vector<BlockSpec>& blocks) {
+  int cur = base;
+  for (int depth = 0; depth < NLEVEL; ++depth) {
+    const int mult = CH_MULT[depth];
+    for (int i = 0; i < DEPTH_MULT; ++i) {
+      blocks.push_back({"stem.blocks." + std::to_string(blocks.size()), cur, mult * base, RESIZE_NONE, 2, false});
+      cur = mult * base;
+    }
+    blocks.push_back({"stem.blocks." + std::to_string(blocks.size()), cur, cur, RESIZE_AVG2, 2, false});
+  }
+}
+
 void block_params(std::vector<ParamDef>& out, const std::string& p, const BlockSpec& s, int emb, bool dropout) {
   const std::string pre = p.empty() ? "" : p + ".";
   out.push_back({pre + "pre_cond.0.0.weight", {s.cin}});
@@ -134,6 +147,15 @@ struct PackedConv {
   }
 };
 
+// weights of the transposed convolution (gradient w.r.t. the input): Wt[ci][co][k] = W[co][ci][K-1-k]
+std::vector<float> transpose_flip(const float* W, int Cout, int Cin, int ktaps) {
+  std::vector<float> t((size_t)Cout * Cin * ktaps);
+  for (int co = 0; co < Cout; ++co)
+    for (int ci = 0; ci < Cin; ++ci)
+      for (int k = 0; k < ktaps; ++k) t[((size_t)ci * Cout + co) * ktaps + k] = W[((size_t)co * Cin + ci) * ktaps + (ktaps - 1 - k)];
+  return t;
+}
+
 double lscale(int lshift) { return lshift >= 0 ? 1.0 / (double)(1 << lshift) : (double)(1 << -lshift); }
 int shiftL(int L, int lshift) { return lshift >= 0 ? (L >> lshift) : (L << -lshift); }
 int ntiles_of(int L, int rows = STAT_TILE) { return (L + rows - 1) / rows; }
@@ -188,8 +210,21 @@ class Builder {
   int stat_rows(const TensorH& t) const { return tile_rows_.at(t.id); }
   void retain(const TensorH& t) { refs_[t.id]++; }
   void release(const TensorH& t) {
+    if (persist) return;  // forward tensors of a model with a backward pass stay resident
     if (--refs_[t.id] == 0 && !m_->cfg.debug_taps) arena_free(offs_[t.id], sizes_[t.id]);
   }
+  bool persist = false;
+  size_t alloc_stats(int C, int lshift) {
+    const size_t off = stats_floats;
+    stats_floats += (size_t)maxB_ * ntiles_of(shiftL(maxL_, lshift), MIN_TILE_ROWS) * C * 2;
+    return off;
+  }
+  // what the backward pass needs to know about one forward ResBlock
+  struct BlockRec {
+    BlockSpec s;
+    TensorH x, h1, out;
+    size_t ss1 = 0, ss2 = 0, mr1 = 0, mr2 = 0;
+  };
   size_t alloc_ss(int C) {
     const size_t off = ss_floats;
     ss_floats += (size_t)maxB_ * C * 2;
@@ -211,7 +246,7 @@ class Builder {
 
   // ---- ops ---------------------------------------------------------------------------
   void add_gn(const std::vector<TensorH>& srcs, const std::string& gn_name, bool film, int film_off, int film_stride,
-              size_t film_misc_off, size_t ss_off) {
+              size_t film_misc_off, size_t ss_off, bool want_mr = false, size_t mr_off = 0) {
     int Ctot = 0;
     for (auto& s : srcs) Ctot += s.C;
     const size_t g_off = blob_f32(gn_name + ".weight");
@@ -223,7 +258,7 @@ class Builder {
     std::vector<int> SR;
     for (auto& t : srcs) SR.push_back(stat_rows(t));
     m_->meta.push_back({"gn_prepare", gn_name + " C=" + std::to_string(Ctot) + " L>>" + std::to_string(lshift), 0, 0, 0});
-    m_->ops.push_back([=](const RunCtx& c) -> int {
+    m_->add_op([=](const RunCtx& c) -> int {
       GnArgs a{};
       const int L = shiftL(c.Lbase, lshift);
       a.nsrc = (int)S.size();
@@ -237,6 +272,7 @@ class Builder {
       a.film_stride = film_stride;
       a.film_off = film_off;
       a.ss = reinterpret_cast<float2*>(self->ssp(ss_off));
+      a.mr = want_mr ? reinterpret_cast<float2*>(self->ssp(mr_off)) : nullptr;
       return launch_gn_prepare(a, c.B, c.st);
     });
   }
@@ -249,7 +285,7 @@ class Builder {
     const TensorH S = src;
     m_->meta.push_back({"xform", "C=" + std::to_string(src.C) + " L>>" + std::to_string(g.lshift) + (avg ? " avg" : ""),
                         src.C * (lscale(src.lshift) + lscale(g.lshift)), 0, 0});
-    m_->ops.push_back([=](const RunCtx& c) -> int {
+    m_->add_op([=](const RunCtx& c) -> int {
       XformArgs a{};
       a.in = self->act(S.off);
       a.ss = reinterpret_cast<const float2*>(self->ssp(ss_off));
@@ -307,7 +343,7 @@ class Builder {
     for (auto& s : segs) desc += (desc.empty() ? "" : "+") + std::to_string(s.C) + "x" + std::to_string(s.ntaps) + (s.resize == RESIZE_AVG2 ? "v" : s.resize == RESIZE_UP2 ? "^" : "") + (s.ntaps == 3 && s.dil > 1 ? "d" + std::to_string(s.dil) : "");
     desc += "->" + std::to_string(Cout) + " L>>" + std::to_string(out.lshift) + (skip ? " +id" : "");
     m_->meta.push_back({"conv", desc, conv_elems, conv_f32, conv_flops});
-    m_->ops.push_back([=](const RunCtx& c) -> int {
+    m_->add_op([=](const RunCtx& c) -> int {
       ConvArgs a{};
       a.nseg = (int)S.size();
       for (int i = 0; i < a.nseg; ++i) {
@@ -349,7 +385,7 @@ class Builder {
   // One reference ResBlock (unet.py:248-316).  `ins` = 1 tensor, or 2 for torch.cat([h, skip], 1).
   // film_misc_off/film_off/film_stride locate this block's (a|b) rows; emb = false for the encoder.
   TensorH resblock(const std::string& p, const BlockSpec& s, const std::vector<TensorH>& ins, bool emb, int film_off, int film_stride,
-                   size_t film_misc_off) {
+                   size_t film_misc_off, BlockRec* rec = nullptr) {
     const std::string pre = p.empty() ? "" : p + ".";
     const int cin = s.cin, cout = s.cout;
     const int in_shift = ins[0].lshift;
@@ -359,7 +395,8 @@ class Builder {
     const bool pre_xform = cout >= 512;
     // GroupNorm 1 coefficients over the (virtually concatenated) input
     const size_t ss1 = alloc_ss(cin);
-    add_gn(ins, pre + "pre_cond.0.0", false, 0, 0, 0, ss1);
+    const size_t mr1 = rec ? alloc_ss(cin) : 0;
+    add_gn(ins, pre + "pre_cond.0.0", false, 0, 0, 0, ss1, rec != nullptr, mr1);
     // conv 1
     TensorH h1 = new_tensor(cout, out_shift, false, true);
     {
@@ -386,7 +423,8 @@ class Builder {
     }
     // GroupNorm 2 (+FiLM) coefficients
     const size_t ss2 = alloc_ss(cout);
-    add_gn({h1}, pre + "pre_cond.3", emb, film_off, film_stride, film_misc_off, ss2);
+    const size_t mr2 = rec ? alloc_ss(cout) : 0;
+    add_gn({h1}, pre + "pre_cond.3", emb, film_off, film_stride, film_misc_off, ss2, rec != nullptr, mr2);
     // conv 2 + skip
     TensorH out = new_tensor(cout, out_shift, false, true);
     {
@@ -423,7 +461,116 @@ class Builder {
       if (pre_xform) release(g2);
     }
     release(h1);
+    if (rec) *rec = BlockRec{s, ins[0], h1, out, ss1, ss2, mr1, mr2};
     return out;
+  }
+
+  // ---- backward pieces (classifier guidance) ------------------------------------------------------
+  void add_bw_act(const TensorH& t, bool up, const TensorH& xf, size_t ss_off, const TensorH& du, size_t part_off) {
+    Builder* self = this;
+    const int prec = m_->cfg.precision;
+    m_->meta.push_back({"bw_act", "C=" + std::to_string(xf.C) + " L>>" + std::to_string(xf.lshift) + (up ? " ^" : ""),
+                        xf.C * (2 * lscale(xf.lshift) + lscale(t.lshift)), 0, 0});
+    m_->add_op([=](const RunCtx& c) -> int {
+      BwActArgs a{};
+      a.t = self->act(t.off);
+      a.xf = self->act(xf.off);
+      a.ss = reinterpret_cast<const float2*>(self->ssp(ss_off));
+      a.du = self->act(du.off);
+      a.partials = self->statp(part_off);
+      a.C = xf.C;
+      a.L = shiftL(c.Lbase, xf.lshift);
+      a.up = up ? 1 : 0;
+      return launch_bw_act(a, c.B, prec, c.st);
+    });
+  }
+  size_t add_gn_bw(int C, int lshift, size_t part_off, size_t ss_off, size_t mr_off) {
+    const size_t coef = alloc_misc((size_t)maxB_ * C * 4);
+    Builder* self = this;
+    const int groups = gn_groups(C);
+    m_->meta.push_back({"gn_bw", "C=" + std::to_string(C) + " L>>" + std::to_string(lshift), 0, 0, 0});
+    m_->add_op([=](const RunCtx& c) -> int {
+      GnBwArgs a{};
+      const int L = shiftL(c.Lbase, lshift);
+      a.partials = self->statp(part_off);
+      a.ntiles = ntiles_of(L);
+      a.C = C;
+      a.groups = groups;
+      a.inv_count = 1.0 / ((double)(C / groups) * (double)L);
+      a.ss = reinterpret_cast<const float2*>(self->ssp(ss_off));
+      a.mr = reinterpret_cast<const float2*>(self->ssp(mr_off));
+      a.coef = reinterpret_cast<float4*>(self->miscp(coef));
+      return launch_gn_bw(a, c.B, c.st);
+    });
+    return coef;
+  }
+  void add_bw_affine(const TensorH& du, const TensorH& xf, size_t coef, const TensorH* skip, bool skip_half, const TensorH* extra,
+                     const TensorH& out) {
+    Builder* self = this;
+    const int prec = m_->cfg.precision;
+    const bool has_skip = skip != nullptr, has_extra = extra != nullptr;
+    const TensorH K = skip ? *skip : TensorH{}, E = extra ? *extra : TensorH{};
+    m_->meta.push_back({"bw_affine", "C=" + std::to_string(xf.C) + " L>>" + std::to_string(xf.lshift),
+                        xf.C * lscale(xf.lshift) * (3 + (has_extra ? 1 : 0)) + (has_skip ? K.C * lscale(K.lshift) : 0.0), 0, 0});
+    m_->add_op([=](const RunCtx& c) -> int {
+      BwAffineArgs a{};
+      a.du = self->act(du.off);
+      a.xf = self->act(xf.off);
+      a.coef = reinterpret_cast<const float4*>(self->miscp(coef));
+      a.skip = has_skip ? self->act(K.off) : nullptr;
+      a.skip_half = skip_half ? 1 : 0;
+      a.extra = has_extra ? self->act(E.off) : nullptr;
+      a.out = self->act(out.off);
+      a.C = xf.C;
+      a.L = shiftL(c.Lbase, xf.lshift);
+      return launch_bw_affine(a, c.B, prec, c.st);
+    });
+  }
+  // plain convolution of a raw tensor with transposed weights (no prologue, no statistics, zero bias)
+  void add_conv_t(const TensorH& src, const float* W, int Cout_fwd, int Cin_fwd, int ktaps, int dil, const TensorH& out) {
+    const std::vector<float> Wt = transpose_flip(W, Cout_fwd, Cin_fwd, ktaps);
+    PackedConv pk;
+    SegSpec g{src, 0, Cout_fwd, ktaps, dil, RESIZE_NONE, false, 0, 0, 0, 0};
+    g.w_off = pk.append(Wt.data(), Cin_fwd, Cout_fwd, ktaps, 0, Cout_fwd);
+    add_conv({g}, pk, std::vector<float>(Cin_fwd, 0.f), Cin_fwd, out, nullptr, 0);
+  }
+
+  // Gradient of one ResBlock with respect to its input (no concatenation, resize none / avg-pool):
+  //   out = skip(resize(x)) + conv2(gelu(GN2(conv1(resize(gelu(GN1(x)))))))       (unet.py:307-316)
+  // consumes `dout` (released) and returns dx.
+  TensorH resblock_backward(const BlockRec& r, const TensorH& dout) {
+    const BlockSpec& s = r.s;
+    const std::string pre = s.prefix + ".";
+    const int cin = s.cin, cout = s.cout;
+    const int in_shift = r.x.lshift, out_shift = r.out.lshift;
+    const bool down = s.resize == RESIZE_AVG2;
+    // d gelu2 = conv2^T(dout);  du2 = . * gelu'(u2);  d h1 = GN2 backward
+    TensorH t1 = new_tensor(cout, out_shift, false, false);
+    const std::string c2 = pre + (cfg_dropout(m_->cfg) ? "post_cond.2" : "post_cond.1");
+    add_conv_t(dout, P(c2 + ".weight"), cout, cout, 3, s.dil, t1);
+    const size_t pa = alloc_stats(cout, out_shift);
+    add_bw_act(t1, false, r.h1, r.ss2, t1, pa);
+    const size_t cf2 = add_gn_bw(cout, out_shift, pa, r.ss2, r.mr2);
+    add_bw_affine(t1, r.h1, cf2, nullptr, false, nullptr, t1);
+    // d resize(gelu1) = conv1^T(d h1);  du1 = resize^T(.) * gelu'(u1);  dx = GN1 backward + skip path
+    TensorH t2 = new_tensor(cin, out_shift, false, false);
+    add_conv_t(t1, P(pre + "pre_cond.2.weight"), cout, cin, 3, 1, t2);
+    release(t1);
+    TensorH du1 = down ? new_tensor(cin, in_shift, false, false) : t2;
+    const size_t pb = alloc_stats(cin, in_shift);
+    add_bw_act(t2, down, r.x, r.ss1, du1, pb);
+    if (down) release(t2);
+    const size_t cf1 = add_gn_bw(cin, in_shift, pb, r.ss1, r.mr1);
+    if (cin != cout) {
+      TensorH t3 = new_tensor(cin, out_shift, false, false);
+      add_conv_t(dout, P(pre + "skip.1.weight"), cout, cin, 1, 1, t3);
+      add_bw_affine(du1, r.x, cf1, nullptr, false, &t3, du1);
+      release(t3);
+    } else {
+      add_bw_affine(du1, r.x, cf1, &dout, down, nullptr, du1);
+    }
+    release(dout);
+    return du1;
   }
 
   void tap(const std::string& name, const TensorH& t) { m_->taps.push_back({name, t}); }
@@ -522,6 +669,25 @@ int enumerate_params(const vqvs_cfg& c, std::vector<ParamDef>& out) {
   } else if (c.kind == VQVS_KIND_RESBLOCK) {
     BlockSpec s{"", c.rb_cin, c.rb_cout, c.rb_resize, c.rb_dilation, false};
     block_params(out, "", s, c.rb_emb_channels, drop);
+  } else if (c.kind == VQVS_KIND_CLASSIFIER) {  // classifier.py:18-104, 131-150
+    const int E = 4 * base, cur = 8 * base, F = 16 * base;
+    out.push_back({"stem.time_embed.proj.weight", {E, E}});
+    out.push_back({"stem.time_embed.proj.bias", {E}});
+    out.push_back({"stem.time_embed_extra.1.weight", {E, E}});
+    out.push_back({"stem.time_embed_extra.1.bias", {E}});
+    out.push_back({"stem.in_conv.weight", {base, 1, 3}});
+    out.push_back({"stem.in_conv.bias", {base}});
+    std::vector<BlockSpec> blocks;
+    classifier_blocks(base, blocks);
+    for (auto& s : blocks) block_params(out, s.prefix, s, E, false);
+    out.push_back({"stem.out.0.0.weight", {cur}});
+    out.push_back({"stem.out.0.0.bias", {cur}});
+    out.push_back({"stem.out.1.qkv_proj.weight", {3 * cur, cur, 1}});
+    out.push_back({"stem.out.1.qkv_proj.bias", {3 * cur}});
+    out.push_back({"stem.out.1.c_proj.weight", {F, cur, 1}});
+    out.push_back({"stem.out.1.c_proj.bias", {F}});
+    out.push_back({"out.1.weight", {c.num_labels, F}});
+    out.push_back({"out.1.bias", {c.num_labels}});
   } else {
     VQVS_FAIL(VQVS_ERR_ARG, "unknown model kind %d", c.kind);
   }
@@ -545,6 +711,9 @@ static int check_cfg(const vqvs_cfg& c) {
   if (c.kind == VQVS_KIND_PREDICTOR) {
     if (c.out_channels != 1 && (c.out_channels % 32)) VQVS_FAIL(VQVS_ERR_ARG, "out_channels must be 1 or a multiple of 32");
     if (c.cond_channels % 32) VQVS_FAIL(VQVS_ERR_ARG, "cond_channels must be a multiple of 32");
+  } else if (c.kind == VQVS_KIND_CLASSIFIER) {
+    if (c.num_labels < 1 || c.num_labels > 8192) VQVS_FAIL(VQVS_ERR_ARG, "classifier num_labels must be in 1..8192 (got %d)", c.num_labels);
+    if (c.max_T % 512) VQVS_FAIL(VQVS_ERR_ARG, "classifier max_T must be a multiple of 512 (got %d)", c.max_T);
   } else {
     if (c.out_channels % 32 || c.out_channels < 32) VQVS_FAIL(VQVS_ERR_ARG, "encoder out_channels must be a multiple of 32");
   }
@@ -569,7 +738,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
     TensorH x = b.new_tensor(c.rb_cin, 0, false, true);
     const int Cin = c.rb_cin;
     m->meta.push_back({"nct_to_ntc", "", 0, 0, 0});
-    m->ops.push_back([=](const RunCtx& r) -> int {
+    m->add_op([=](const RunCtx& r) -> int {
       return launch_nct_to_ntc(r.x, bp->act(x.off), bp->statp(x.stats_off), r.B, Cin, r.Lbase, ntiles_of(r.Lbase), prec, r.st);
     });
     size_t film_misc = 0;
@@ -580,7 +749,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
       const size_t bias_off = b.blob_f32("cond_layers.1.bias");
       const int R = 2 * c.rb_cout;
       m->meta.push_back({"film", "", 0, 0, 0});
-      m->ops.push_back([=](const RunCtx& r) -> int {
+      m->add_op([=](const RunCtx& r) -> int {
         if (!r.emb) VQVS_FAIL(VQVS_ERR_ARG, "resblock handle was built with an embedding; d_emb is NULL");
         if (int e = launch_gelu_rows(r.emb, bp->miscp(gemb), r.B * E, r.st)) return e;
         FilmArgs f{bp->miscp(gemb), reinterpret_cast<const float*>(bp->wp(w_off)), reinterpret_cast<const float*>(bp->wp(bias_off)),
@@ -591,7 +760,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
     TensorH y = b.resblock("", s, {x}, E != 0, 0, 2 * c.rb_cout, film_misc);
     const int Cout = c.rb_cout;
     m->meta.push_back({"ntc_to_nct", "", 0, 0, 0});
-    m->ops.push_back([=](const RunCtx& r) -> int {
+    m->add_op([=](const RunCtx& r) -> int {
       return launch_ntc_to_nct(bp->act(y.off), r.out, r.B, Cout, shiftL(r.Lbase, y.lshift), prec, r.st);
     });
     b.tap("out", y);
@@ -611,7 +780,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
     const size_t gemb_off = b.alloc_misc((size_t)c.max_batch * E);
     const int NL = c.num_labels;
     m->meta.push_back({"time_embed", "", 0, 0, 0});
-    m->ops.push_back([=](const RunCtx& r) -> int {
+    m->add_op([=](const RunCtx& r) -> int {
       TimeEmbedArgs a{};
       a.ts = r.ts;
       a.freqs = reinterpret_cast<const float*>(bp->wp(freq_off));
@@ -647,7 +816,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
     const size_t ball_off = b.blob.add(ball.data(), ball.size() * 4);
     const size_t film_off = b.alloc_misc((size_t)c.max_batch * R);
     m->meta.push_back({"film", "", 0, 0, 0});
-    m->ops.push_back([=](const RunCtx& r) -> int {
+    m->add_op([=](const RunCtx& r) -> int {
       FilmArgs f{bp->miscp(gemb_off), reinterpret_cast<const float*>(bp->wp(wall_off)), reinterpret_cast<const float*>(bp->wp(ball_off)),
                  bp->miscp(film_off), E, R};
       return launch_film(f, r.B, r.st);
@@ -659,7 +828,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
       TensorH ct = b.new_tensor(c.cond_channels, 8, false, false);
       const int CC = c.cond_channels;
       m->meta.push_back({"nct_to_ntc", "", 0, 0, 0});
-      m->ops.push_back([=](const RunCtx& r) -> int {
+      m->add_op([=](const RunCtx& r) -> int {
         return launch_nct_to_ntc(r.cond, bp->act(ct.off), nullptr, r.B, CC, r.Lbase >> 8, 0, prec, r.st);
       });
       condp = b.new_tensor(base, 8, false, false);
@@ -676,7 +845,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
       const size_t w = b.blob_f32("in_conv.weight"), bi = b.blob_f32("in_conv.bias");
       const TensorH cp = condp;
       m->meta.push_back({"in_conv", "1->" + std::to_string(base), base + (has_cond ? base / 256.0 : 0.0), 4.0, 0});
-      m->ops.push_back([=](const RunCtx& r) -> int {
+      m->add_op([=](const RunCtx& r) -> int {
         InConvArgs a{};
         a.x = r.x;
         a.w = reinterpret_cast<const float*>(bp->wp(w));
@@ -736,7 +905,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
       const size_t w = b.blob.add(wt.data(), wt.size() * 4);
       const float bias = b.P("out.1.bias")[0];
       m->meta.push_back({"out_conv", std::to_string(base) + "->1", (double)base, 4.0, 0});
-      m->ops.push_back([=](const RunCtx& r) -> int {
+      m->add_op([=](const RunCtx& r) -> int {
         OutConvArgs a{};
         a.in = bp->act(h.off);
         a.ss = reinterpret_cast<const float2*>(bp->ssp(ss));
@@ -756,8 +925,152 @@ int build_model(vqvs_model* m, const float* const* hp) {
       b.add_conv({g}, pk, std::vector<float>(bb, bb + c.out_channels), c.out_channels, o, nullptr, 0);
       const int OC = c.out_channels;
       m->meta.push_back({"ntc_to_nct", "", 0, 0, 0});
-      m->ops.push_back([=](const RunCtx& r) -> int { return launch_ntc_to_nct(bp->act(o.off), r.out, r.B, OC, r.Lbase, 0, r.st); });
+      m->add_op([=](const RunCtx& r) -> int { return launch_ntc_to_nct(bp->act(o.off), r.out, r.B, OC, r.Lbase, 0, r.st); });
     }
+  } else if (c.kind == VQVS_KIND_CLASSIFIER) {
+    // Classifier.forward (classifier.py:31-36, 111-121) + the input gradient used by cond_fn (sample_diffusion.py:34-42)
+    const int E = 4 * base, cur = 8 * base, F = 16 * base, NL = c.num_labels;
+    std::vector<BlockSpec> blocks;
+    classifier_blocks(base, blocks);
+    b.persist = true;  // the backward pass re-reads every block input, h1 and their GroupNorm coefficients
+    std::vector<float> freqs(E / 2);
+    for (int i = 0; i < E / 2; ++i)
+      freqs[i] = (float)(std::exp((double)(float)(-std::log(100.0 / 0.1)) * (double)i / (double)(E / 2 - 1))) * 100.0f;
+    const size_t freq_off = b.blob.add(freqs.data(), freqs.size() * 4);
+    const size_t w1 = b.blob_f32_transposed(b.P("stem.time_embed.proj.weight"), E, E), b1 = b.blob_f32("stem.time_embed.proj.bias");
+    const size_t w2 = b.blob_f32_transposed(b.P("stem.time_embed_extra.1.weight"), E, E), b2 = b.blob_f32("stem.time_embed_extra.1.bias");
+    const size_t emb_off = b.alloc_misc((size_t)c.max_batch * E);
+    const size_t gemb_off = b.alloc_misc((size_t)c.max_batch * E);
+    m->meta.push_back({"time_embed", "", 0, 0, 0});
+    m->add_op([=](const RunCtx& r) -> int {
+      TimeEmbedArgs a{};
+      a.ts = r.ts;
+      a.freqs = reinterpret_cast<const float*>(bp->wp(freq_off));
+      a.w1 = reinterpret_cast<const float*>(bp->wp(w1));
+      a.b1 = reinterpret_cast<const float*>(bp->wp(b1));
+      a.w2 = reinterpret_cast<const float*>(bp->wp(w2));
+      a.b2 = reinterpret_cast<const float*>(bp->wp(b2));
+      a.emb = bp->miscp(emb_off);
+      a.gemb = bp->miscp(gemb_off);
+      a.E = E;
+      return launch_time_embed(a, r.B, r.st);
+    });
+    std::vector<int> film_row(blocks.size());
+    int R = 0;
+    std::vector<float> Wall, ball;
+    for (size_t i = 0; i < blocks.size(); ++i) {
+      film_row[i] = R;
+      const float* W = b.P(blocks[i].prefix + ".cond_layers.1.weight");
+      const float* bb = b.P(blocks[i].prefix + ".cond_layers.1.bias");
+      const int rows = 2 * blocks[i].cout;
+      Wall.insert(Wall.end(), W, W + (size_t)rows * E);
+      ball.insert(ball.end(), bb, bb + rows);
+      R += rows;
+    }
+    const size_t wall_off = b.blob_f32_transposed(Wall.data(), R, E);
+    const size_t ball_off = b.blob.add(ball.data(), ball.size() * 4);
+    const size_t film_off = b.alloc_misc((size_t)c.max_batch * R);
+    m->meta.push_back({"film", "", 0, 0, 0});
+    m->add_op([=](const RunCtx& r) -> int {
+      FilmArgs f{bp->miscp(gemb_off), reinterpret_cast<const float*>(bp->wp(wall_off)), reinterpret_cast<const float*>(bp->wp(ball_off)),
+                 bp->miscp(film_off), E, R};
+      return launch_film(f, r.B, r.st);
+    });
+    TensorH h = b.new_tensor(base, 0, false, true);
+    const size_t inw = b.blob_f32("stem.in_conv.weight"), inb = b.blob_f32("stem.in_conv.bias");
+    m->meta.push_back({"in_conv", "1->" + std::to_string(base), (double)base, 4.0, 0});
+    m->add_op([=](const RunCtx& r) -> int {
+      InConvArgs a{};
+      a.x = r.x;
+      a.w = reinterpret_cast<const float*>(bp->wp(inw));
+      a.bias = reinterpret_cast<const float*>(bp->wp(inb));
+      a.condp = nullptr;
+      a.cond_rate = 256;
+      a.out = bp->act(h.off);
+      a.stats = bp->statp(h.stats_off);
+      a.C = base;
+      a.T = r.Lbase;
+      a.ntiles = ntiles_of(r.Lbase);
+      return launch_in_conv(a, r.B, prec, r.st);
+    });
+    b.tap("stem.in_conv", h);
+    std::vector<Builder::BlockRec> recs(blocks.size());
+    for (size_t i = 0; i < blocks.size(); ++i) {
+      h = b.resblock(blocks[i].prefix, blocks[i], {h}, true, film_row[i], R, film_off, &recs[i]);
+      b.tap(blocks[i].prefix, h);
+    }
+    // ---- head: GroupNorm + GELU + attention pool (query token only) + c_proj + GELU + Linear, and its backward
+    const size_t ssh = b.alloc_ss(cur), mrh = b.alloc_ss(cur);
+    b.add_gn({h}, "stem.out.0.0", false, 0, 0, 0, ssh, true, mrh);
+    const int ch = std::min(cur, 64), heads = cur / ch;
+    const float* Wqkv = b.P("stem.out.1.qkv_proj.weight");  // [3*cur][cur][1]: q rows, k rows, v rows
+    const float* bqkv = b.P("stem.out.1.qkv_proj.bias");
+    const double sc2 = 1.0 / std::sqrt((double)ch);  // both q and k carry ch^-1/4 (classifier.py:181-186)
+    std::vector<float> rvec((size_t)heads * cur), c0(heads);
+    for (int hd = 0; hd < heads; ++hd) {
+      double cc = 0.0;
+      for (int j = 0; j < ch; ++j) cc += (double)bqkv[hd * ch + j] * (double)bqkv[cur + hd * ch + j];
+      c0[hd] = (float)(cc * sc2);
+      for (int ci = 0; ci < cur; ++ci) {
+        double acc = 0.0;
+        for (int j = 0; j < ch; ++j) acc += (double)bqkv[hd * ch + j] * (double)Wqkv[(size_t)(cur + hd * ch + j) * cur + ci];
+        rvec[(size_t)hd * cur + ci] = (float)(acc * sc2);
+      }
+    }
+    const size_t r_off = b.blob.add(rvec.data(), rvec.size() * 4), c0_off = b.blob.add(c0.data(), c0.size() * 4);
+    const size_t wv_off = b.blob.add(Wqkv + (size_t)2 * cur * cur, (size_t)cur * cur * 4);
+    const size_t bv_off = b.blob.add(bqkv + 2 * cur, (size_t)cur * 4);
+    const size_t wc_off = b.blob_f32("stem.out.1.c_proj.weight"), bc_off = b.blob_f32("stem.out.1.c_proj.bias");
+    const size_t wl_off = b.blob_f32("out.1.weight"), bl_off = b.blob_f32("out.1.bias");
+    b.persist = false;
+    TensorH dh = b.new_tensor(cur, h.lshift, false, false);
+    const int groups_h = gn_groups(cur);
+    const TensorH hl = h;
+    m->meta.push_back({"cls_head", "C=" + std::to_string(cur), 0, 0, 0});
+    m->add_op([=](const RunCtx& r) -> int {
+      HeadArgs a{};
+      a.h = bp->act(hl.off);
+      a.ss = reinterpret_cast<const float2*>(bp->ssp(ssh));
+      a.mr = reinterpret_cast<const float2*>(bp->ssp(mrh));
+      a.C = cur;
+      a.L = shiftL(r.Lbase, hl.lshift);
+      a.heads = heads;
+      a.F = F;
+      a.NL = NL;
+      a.groups = groups_h;
+      a.inv_count = 1.0 / ((double)(cur / groups_h) * (double)a.L);
+      a.r = reinterpret_cast<const float*>(bp->wp(r_off));
+      a.c0 = reinterpret_cast<const float*>(bp->wp(c0_off));
+      a.wv = reinterpret_cast<const float*>(bp->wp(wv_off));
+      a.bv = reinterpret_cast<const float*>(bp->wp(bv_off));
+      a.wc = reinterpret_cast<const float*>(bp->wp(wc_off));
+      a.bc = reinterpret_cast<const float*>(bp->wp(bc_off));
+      a.wl = reinterpret_cast<const float*>(bp->wp(wl_off));
+      a.bl = reinterpret_cast<const float*>(bp->wp(bl_off));
+      a.logits = r.out;
+      a.labels = r.backward ? r.labels : nullptr;
+      a.gscale = r.gscale;
+      a.dh = bp->act(dh.off);
+      return launch_cls_head(a, r.B, prec, r.st);
+    });
+    // ---- backward schedule (phase 1): blocks in reverse, then the 1 -> base input convolution
+    m->cur_phase = 1;
+    TensorH g = dh;
+    for (size_t i = blocks.size(); i-- > 0;) g = b.resblock_backward(recs[i], g);
+    {
+      const TensorH gi = g;
+      m->meta.push_back({"in_conv_bw", std::to_string(base) + "->1", (double)base, 4.0, 0});
+      m->add_op([=](const RunCtx& r) -> int {
+        InConvBwArgs a{};
+        a.dh = bp->act(gi.off);
+        a.w = reinterpret_cast<const float*>(bp->wp(inw));
+        a.out = r.grad_out;
+        a.C = base;
+        a.T = r.Lbase;
+        return launch_in_conv_bw(a, r.B, prec, r.st);
+      });
+    }
+    m->cur_phase = 0;
   } else {  // encoder (unet.py:229-241)
     std::vector<BlockSpec> blocks;
     encoder_blocks(base, blocks);
@@ -765,7 +1078,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
     {
       const size_t w = b.blob_f32("in_conv.weight"), bi = b.blob_f32("in_conv.bias");
       m->meta.push_back({"in_conv", "1->" + std::to_string(base), (double)base, 4.0, 0});
-      m->ops.push_back([=](const RunCtx& r) -> int {
+      m->add_op([=](const RunCtx& r) -> int {
         InConvArgs a{};
         a.x = r.x;
         a.w = reinterpret_cast<const float*>(bp->wp(w));
@@ -798,7 +1111,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
     b.add_conv({g}, pk, std::vector<float>(bb, bb + c.out_channels), c.out_channels, o, nullptr, 0);
     const int OC = c.out_channels;
     m->meta.push_back({"ntc_to_nct", "", 0, 0, 0});
-    m->ops.push_back([=](const RunCtx& r) -> int { return launch_ntc_to_nct(bp->act(o.off), r.out, r.B, OC, r.Lbase >> 8, 0, r.st); });
+    m->add_op([=](const RunCtx& r) -> int { return launch_ntc_to_nct(bp->act(o.off), r.out, r.B, OC, r.Lbase >> 8, 0, r.st); });
   }
 
   for (auto& mt : m->meta) {
@@ -835,15 +1148,17 @@ int run_model(vqvs_model* m, const RunCtx& ctx) {
     }
     VQVS_HIP(hipEventRecord(m->events[0], ctx.st));
     for (size_t i = 0; i < m->ops.size(); ++i) {
-      if (int e = m->ops[i](ctx)) return e;
+      if (m->op_phase[i] == 0 || ctx.backward)
+        if (int e = m->ops[i](ctx)) return e;
       VQVS_HIP(hipEventRecord(m->events[i + 1], ctx.st));
     }
     m->last_B = ctx.B;
     m->last_L = ctx.Lbase;
     return 0;
   }
-  for (auto& op : m->ops)
-    if (int e = op(ctx)) return e;
+  for (size_t i = 0; i < m->ops.size(); ++i)
+    if (m->op_phase[i] == 0 || ctx.backward)
+      if (int e = m->ops[i](ctx)) return e;
   m->last_B = ctx.B;
   m->last_L = ctx.Lbase;
   return 0;

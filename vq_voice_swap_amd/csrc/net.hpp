@@ -44,6 +44,10 @@ struct RunCtx {
   const int64_t* labels = nullptr;
   const float* emb = nullptr;  // resblock handle: external embedding
   float* out = nullptr;
+  // classifier handles: logits [B][num_labels]; with backward, grad_out [B][T] = gscale * d log p(labels) / dx
+  bool backward = false;
+  float gscale = 1.0f;
+  float* grad_out = nullptr;
   hipStream_t st = nullptr;
 };
 
@@ -74,6 +78,13 @@ struct vqvs_model {
     double flops = 0;      // per clip per unit of base length
   };
   std::vector<OpMeta> meta;  // parallel to ops
+  // ops of phase 0 always run; phase 1 ops (the backward schedule of a classifier handle) only when asked for
+  std::vector<uint8_t> op_phase;
+  int cur_phase = 0;
+  void add_op(std::function<int(const vqvs::RunCtx&)> fn) {
+    ops.push_back(std::move(fn));
+    op_phase.push_back((uint8_t)cur_phase);
+  }
   bool profiling = false;
   std::vector<hipEvent_t> events;  // ops.size() + 1 when profiling
   std::vector<vqvs::TapDef> taps;
