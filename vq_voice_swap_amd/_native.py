@@ -14,7 +14,7 @@ import subprocess
 from typing import Dict, List, Optional, Sequence, Tuple
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvqvs_hip.so")
+LIB_PATH = os.environ.get("VQVS_LIB_PATH") or os.path.join(_HERE, "libvqvs_hip.so")  # override: instrumented builds (tools/)
 CSRC = os.path.join(_HERE, "csrc")
 
 KIND_PREDICTOR, KIND_ENCODER, KIND_RESBLOCK, KIND_CLASSIFIER = 0, 1, 2, 3

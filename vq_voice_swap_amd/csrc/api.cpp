@@ -327,3 +327,8 @@ int vqvs_profile_read(vqvs_model* m, float* h_ms, int cap) {
 }
 
 }  // extern "C"
+
+#ifdef VQVS_TIMING
+namespace vqvs { int conv_timing_read(unsigned long long* out16, int reset); }
+extern "C" int vqvs_debug_conv_timing(unsigned long long* h_out16, int reset) { return vqvs::conv_timing_read(h_out16, reset); }
+#endif

@@ -21,6 +21,20 @@
 //                hi*hi + lo*hi + hi*lo with fp32 accumulation (drops only lo*lo ~ 2^-18).
 #include "kernels.hpp"
 
+// Optional in-kernel phase timing (tools/conv_phases.py; build with -DVQVS_TIMING into a separate library):
+// every wave accumulates s_memtime deltas per phase and adds them to g_conv_timing at exit.
+#ifdef VQVS_TIMING
+__device__ unsigned long long g_conv_timing[24];
+#define TMARK(i)                                                    \
+  {                                                                 \
+    const unsigned long long _t = __builtin_amdgcn_s_memtime();     \
+    tacc[i] += _t - tlast;                                          \
+    tlast = _t;                                                     \
+  }
+#else
+#define TMARK(i)
+#endif
+
 namespace vqvs {
 
 namespace {
@@ -82,14 +96,23 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, lo
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, n, 0x00020000);
 }
 
-// everything a thread needs to know about one K iteration (segment, chunk)
+// Everything a thread needs to know about the segment it is staging.  It is rebuilt only when the K loop crosses
+// into the next segment (<= 3 times per tile): the per-chunk work is then `ch`-relative address arithmetic, with no
+// scalar loads of the argument block inside the loop.
 struct IterGeom {
-  int s, ch;        // segment, chunk
+  int s, ch, nch;   // segment, chunk, chunks in this segment
   int ntaps, d;     // taps and dilation (0 for 1-tap)
   int nrows;        // LDS rows to stage
   int base_time;    // time index of LDS row 0 (in the staged resolution)
   int row_bound;    // valid time range [0, row_bound)
-  bool up, avg, xform;
+  int up, avg, xform;  // (ints, not bools: keeps the struct free of sub-dword tails, so copies stay in registers)
+  const void* clip;           // this clip's rows of the source tensor ...
+  int clip_bytes;             // ... and their size (the buffer descriptor is rebuilt from these two at each use)
+  int base_off, step;         // byte offset of the thread's first (row, octet) item in chunk 0; bytes between its items
+  const float2* ssp;          // (scale, shift) of the thread's octet in chunk 0
+  const void* avg_src;        // avg-pool path: the thread's octet of row 0, chunk 0
+  int Csrc;
+  int wbase, wstep;           // byte offset of chunk 0 in the packed weights, bytes per chunk
 };
 
 template <typename T, bool X3, int WN, int HALO, bool SKIPV, int WGN, int WM>
@@ -105,6 +128,10 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
   constexpr int BUF_BYTES = PLANES * (ACT_BYTES + W_BYTES);
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
+#ifdef VQVS_TIMING
+  unsigned long long tacc[18] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = __builtin_amdgcn_s_memtime();
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = (tid >> 6) & 3;   // position along time
@@ -150,11 +177,17 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
   int niter = 0;
   for (int s = 0; s < a.nseg; ++s) niter += a.seg[s].C >> 5;
 
-  auto geom = [&](int s, int ch) {
+  auto geom = [&](int s) {
     IterGeom g;
-    const SegDesc& sg = a.seg[s];
+    // field-wise selects over the three argument-block entries: one batch of scalar loads, no dynamically indexed copy
+    struct { const void* src; const float2* ss; long long w_off; int Csrc, c0, C, Lsrc, ntaps, dil, resize, ss_stride, ss_c0; } sg;
+#define VQVS_SEGF(f) sg.f = s == 0 ? a.seg[0].f : (s == 1 ? a.seg[1].f : a.seg[2].f)
+    VQVS_SEGF(src); VQVS_SEGF(ss); VQVS_SEGF(w_off); VQVS_SEGF(Csrc); VQVS_SEGF(c0); VQVS_SEGF(C); VQVS_SEGF(Lsrc);
+    VQVS_SEGF(ntaps); VQVS_SEGF(dil); VQVS_SEGF(resize); VQVS_SEGF(ss_stride); VQVS_SEGF(ss_c0);
+#undef VQVS_SEGF
     g.s = s;
-    g.ch = ch;
+    g.ch = 0;
+    g.nch = sg.C >> 5;
     g.ntaps = sg.ntaps;
     g.d = (sg.ntaps == 3) ? sg.dil : 0;
     g.up = sg.resize == RESIZE_UP2;
@@ -163,6 +196,22 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
     g.nrows = g.up ? (TTO / 2 + 2) : (TTO + 2 * g.d);
     g.base_time = g.up ? ((t0 >> 1) - 1) : (t0 - g.d);
     g.row_bound = g.avg ? a.Lout : sg.Lsrc;
+    const T* const clip = reinterpret_cast<const T*>(sg.src) + (size_t)b * sg.Lsrc * sg.Csrc;
+    // byte offset of item i = ((base_time + r_i) * Csrc + c0 + ch*32 + oct*8) * sizeof(T); negative or past-the-end rows
+    // fall outside the descriptor and read as zero (their LDS rows are re-zeroed after the prologue anyway)
+    g.clip = clip;
+    {
+      const long long nb = (long long)sg.Lsrc * sg.Csrc * (int)sizeof(T);
+      g.clip_bytes = nb > 0x7fffffffLL ? 0x7fffffff : (int)nb;
+    }
+    const int row_bytes = sg.Csrc * (int)sizeof(T);
+    g.base_off = (g.base_time * sg.Csrc + sg.c0 + oct * 8) * (int)sizeof(T) + (tid >> 2) * row_bytes;
+    g.step = (NTH / 4) * row_bytes;
+    g.ssp = g.xform ? sg.ss + (size_t)b * sg.ss_stride + sg.ss_c0 + oct * 8 : nullptr;
+    g.avg_src = clip + sg.c0 + oct * 8;
+    g.Csrc = sg.Csrc;
+    g.wbase = (int)(sg.w_off * 2);
+    g.wstep = g.ntaps * a.Cout * 32 * 2;
     return g;
   };
 
@@ -173,30 +222,26 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
   (void)rwl;
 
   auto issue_loads = [&](const IterGeom& g) {
-    const SegDesc& sg = a.seg[g.s];
-    const int cl = g.ch * 32 + oct * 8;
     if (g.xform) {
-      const float2* p = sg.ss + (size_t)b * sg.ss_stride + sg.ss_c0 + cl;
+      const float2* p = g.ssp + g.ch * 32;
 #pragma unroll
       for (int j = 0; j < 4; ++j) rss[j] = *reinterpret_cast<const f32x4*>(p + 2 * j);
     }
+    TMARK(11)
     if (!g.avg) {
-      // byte offset of item i = ((base_time + r_i) * Csrc + c0 + cl) * sizeof(T); negative or past-the-end rows
-      // fall outside the descriptor and read as zero (their LDS rows are re-zeroed after the prologue anyway)
-      const __amdgpu_buffer_rsrc_t rs =
-          make_rsrc(reinterpret_cast<const T*>(sg.src) + (size_t)b * sg.Lsrc * sg.Csrc, (long long)sg.Lsrc * sg.Csrc * (int)sizeof(T));
-      const int row_bytes = sg.Csrc * (int)sizeof(T);
-      const int base = (g.base_time * sg.Csrc + sg.c0 + cl) * (int)sizeof(T) + (tid >> 2) * row_bytes;
-      const int step = (NTH / 4) * row_bytes;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.clip), 0, g.clip_bytes, 0x00020000);
+      const int base = g.base_off + g.ch * (32 * (int)sizeof(T));
 #pragma unroll
-      for (int i = 0; i < NPF; ++i) ra[i].load(rs, base + i * step);
+      for (int i = 0; i < NPF; ++i) ra[i].load(rs, base + i * g.step);
     }
-    const int wbase = (int)((sg.w_off + (long long)g.ch * g.ntaps * a.Cout * 32) * 2);
+    TMARK(12)
+    const int wbase = g.wbase + g.ch * g.wstep;
 #pragma unroll
     for (int i = 0; i < NWV; ++i) {
       rwh[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_wh, w_goff[i] + wbase, 0, 0);
       if constexpr (X3) rwl[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_wl, w_goff[i] + wbase, 0, 0);
     }
+    TMARK(13)
   };
 
   auto store_stage = [&](const IterGeom& g, int buf) {
@@ -235,15 +280,14 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
         }
       }
     } else {  // avg-pool segments (8 of 130 convs): staged synchronously, two source rows per LDS row
-      const SegDesc& sg = a.seg[g.s];
-      const T* const src_c = reinterpret_cast<const T*>(sg.src) + (size_t)b * sg.Lsrc * sg.Csrc + sg.c0 + g.ch * 32 + oct * 8;
+      const T* const src_c = reinterpret_cast<const T*>(g.avg_src) + g.ch * 32;
       for (int r = tid >> 2; r < g.nrows; r += NTH / 4) {
         const int tm = g.base_time + r;
         f32x8 v = f32x8_zero();
         if (tm >= 0 && tm < g.row_bound) {
-          const T* p = src_c + (size_t)(2 * tm) * sg.Csrc;
+          const T* p = src_c + (size_t)(2 * tm) * g.Csrc;
           f32x8 v0 = Elem<T>::load8(p);
-          f32x8 v1 = Elem<T>::load8(p + sg.Csrc);
+          f32x8 v1 = Elem<T>::load8(p + g.Csrc);
           if (g.xform) { v0 = affine_gelu<X3>(v0, sc, sh); v1 = affine_gelu<X3>(v1, sc, sh); }
           v = (v0 + v1) * 0.5f;
         }
@@ -322,17 +366,23 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
 
   // ------------------------------ pipelined K loop ------------------------------
   {
-    int s = 0, ch = 0;
-    IterGeom cur = geom(0, 0);
+    IterGeom cur = geom(0);
+    TMARK(0)  // setup
     issue_loads(cur);
     for (int it = 0; it < niter; ++it) {
       const int buf = it & 1;
+#ifdef VQVS_TIMING
+      TMARK(16)  // loop back-edge
+      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): isolate the wait for the global loads
+      TMARK(2)
+#endif
       store_stage(cur, buf);  // consumes the registers loaded one iteration ago
+      TMARK(3)  // prologue arithmetic + LDS writes
       IterGeom nxt = cur;
       const bool more = it + 1 < niter;
       if (more) {
-        if (++ch == (a.seg[s].C >> 5)) { ch = 0; ++s; }
-        nxt = geom(s, ch);
+        if (++nxt.ch == nxt.nch) nxt = geom(cur.s + 1);
+        TMARK(14)
         issue_loads(nxt);  // in flight across the barrier and the MFMAs below
       } else if (skip_pf) {
 #pragma unroll
@@ -342,8 +392,19 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
           rsk[i].load(rs_skip, (ts * a.skip_C + cg) * (int)sizeof(T));  // rows past the end read as zero and are never stored
         }
       }
+      TMARK(1)
       __syncthreads();
+      TMARK(4)  // barrier
       mfma_stage(cur, buf);
+      TMARK(5)  // LDS fragment reads + MFMA
+#ifdef VQVS_TIMING
+      {
+        float probe;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(probe) : "v"(acc[WM - 1][WN - 1][15]));  // waits for the last MFMA result
+        asm volatile("" ::"v"(probe));
+      }
+      TMARK(17)  // matrix-pipe drain
+#endif
       cur = nxt;
     }
   }
@@ -352,6 +413,7 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
   // accumulators -> LDS tile [256][CT+4] f32 -> whole-row reads: bias, skip, statistics, store.
   float* const ost = reinterpret_cast<float*>(smem);
   __syncthreads();
+  TMARK(6)  // barrier before the epilogue
 #pragma unroll
   for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
@@ -361,7 +423,9 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
         const int row = wave * (WM * 32) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         ost[row * OS + (wvn * WN + nt) * 32 + l31] = acc[mt][nt][r];
       }
+  TMARK(7)  // accumulators -> LDS
   __syncthreads();
+  TMARK(8)
 
   f32x8 s1 = f32x8_zero(), s2 = f32x8_zero();
 #pragma unroll
@@ -389,6 +453,7 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
         Elem<T>::store8(reinterpret_cast<T*>(a.out) + oidx, v);
     }
   }
+  TMARK(9)  // row phase: skip, statistics, stores
   if (a.stats) {
     __syncthreads();
     float* const red = reinterpret_cast<float*>(smem);  // [RPP][CT][2]
@@ -409,6 +474,13 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
       o[1] = t2;
     }
   }
+#ifdef VQVS_TIMING
+  TMARK(10)  // statistics reduce
+  if (lane == 0 && wave == 1 && (blockIdx.x & 15) == 3) {  // a 1/64 sample: the atomics must not become the workload
+    for (int i = 0; i < 18; ++i) atomicAdd(&g_conv_timing[i], tacc[i]);
+    atomicAdd(&g_conv_timing[23], 1ull);
+  }
+#endif
 }
 
 template <bool X3, int WN, int HALO, int WGN = 1, int WM = 2>
@@ -467,6 +539,18 @@ int conv_lds_bytes(int precision, int wn) {
   if (precision == 0) return wn == 2 ? lds_bytes<true, 2, 4>() : lds_bytes<true, 1, 4>();
   return wn == 2 ? lds_bytes<false, 2, 4>() : lds_bytes<false, 1, 4>();
 }
+
+#ifdef VQVS_TIMING
+int conv_timing_read(unsigned long long* out16, int reset) {
+  VQVS_HIP(hipDeviceSynchronize());
+  VQVS_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_conv_timing), 24 * sizeof(unsigned long long)));
+  if (reset) {
+    unsigned long long z[24] = {};
+    VQVS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_conv_timing), z, sizeof(z)));
+  }
+  return 0;
+}
+#endif
 
 int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st) {
   if (a.Cout % 32 != 0 || a.nseg < 1 || a.nseg > 3) VQVS_FAIL(-1, "conv: unsupported shape Cout=%d nseg=%d", a.Cout, a.nseg);
