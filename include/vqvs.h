@@ -40,6 +40,8 @@ extern "C" {
 #define VQVS_KIND_ENCODER 1   /* UNetEncoder    (reference unet.py:187-245) */
 #define VQVS_KIND_RESBLOCK 2  /* one ResBlock   (reference unet.py:248-316); unit-test granularity */
 #define VQVS_KIND_CLASSIFIER 3 /* Classifier   (reference vq_voice_swap/models/classifier.py:18-191), base_channels + num_labels */
+#define VQVS_KIND_ENCPRED 4    /* EncoderPredictor (reference models/encoder_predictor.py:14-75): base_channels, out_channels =
+                                  bottleneck_dim, reserved[1] = downsample_rate, reserved[2] = num_latents */
 
 /* activation storage / arithmetic */
 #define VQVS_PREC_F32 0  /* fp32 activations; convs as 3-term bf16-split MFMA, fp32 accumulate (~2^-17 rel.) */
@@ -110,6 +112,19 @@ int vqvs_classifier_forward(vqvs_model* m, const float* d_x, const float* d_ts, 
  *   d_labels [B] int64, d_grad [B,1,T] f32 out, d_logits [B,num_labels] f32 out or NULL */
 int vqvs_classifier_guidance(vqvs_model* m, const float* d_x, const float* d_ts, const int64_t* d_labels, float scale,
                              float* d_grad, float* d_logits, int B, int T, void* stream);
+
+/* ---- encoder-predictor guidance ---------------------------------------------------
+ * logits = EncoderPredictor.forward(x, ts)   reference models/encoder_predictor.py:43-58: UNetPredictor with a
+ * bottleneck output, nearest down-sampling by `downsample_rate`, 1x1 convolution to num_latents logits.
+ * VQVS_KIND_ENCPRED handles; parameters are named relative to the module ("unet.in_conv.weight", "out.weight").
+ *   d_x [B,1,T] f32, d_ts [B] f32 -> d_logits [B,num_latents,T/rate] f32 */
+int vqvs_encpred_forward(vqvs_model* m, const float* d_x, const float* d_ts, float* d_logits, int B, int T, void* stream);
+/* grad = -scale * d/dx sum_{b,i} cross_entropy(logits[b,:,i], targets[b,i]) -- the cond_fn of VQVAE.decode(enc_pred=...)
+ * (reference vq_vae.py:125-130, encoder_predictor.py:60-64), computed by an explicit backward schedule through the
+ * whole UNet (concatenating, up- and down-sampling blocks).
+ *   d_targets [B,T/rate] int64, d_grad [B,1,T] f32 out, d_logits [B,num_latents,T/rate] f32 out or NULL */
+int vqvs_encpred_guidance(vqvs_model* m, const float* d_x, const float* d_ts, const int64_t* d_targets, float scale,
+                          float* d_grad, float* d_logits, int B, int T, void* stream);
 
 /* ---- DDPM reverse step --------------------------------------------------------
  * x_prev = Diffusion.ddpm_previous(x_t, ts, step, eps, noise, sigma_large, constrain)

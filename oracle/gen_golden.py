@@ -290,6 +290,28 @@ def gen_classifier():
     save("f9_classifier32", x_seed=61, ts=ts, labels=labels, logits=logits.detach(), grad=grad)
 
 
+# ---------------------------------------------------------------- F10 encoder predictor (vq_vae.py:125-130 guidance)
+def gen_encpred():
+    import torch.nn.functional as F
+    from vq_voice_swap.models import EncoderPredictor  # reference
+
+    ep = det_model(EncoderPredictor(base_channels=32, downsample_rate=256, num_latents=96, bottleneck_dim=64))
+    sd = state_of(ep)
+    x = seeded((2, 1, 16384), 71)
+    ts = torch.tensor([0.3, 0.85])
+    targets = torch.randint(0, 96, (2, 64), generator=torch.Generator().manual_seed(72))
+    xg = x.clone().requires_grad_()
+    logits = ep(xg, ts)
+    losses = ep.losses(xg, ts, targets) * targets.shape[-1]       # vq_vae.py:128
+    grad = torch.autograd.grad(losses.sum(), xg)[0] * 1.0 * -1      # vq_vae.py:129-130
+    logits2 = ref_cpu.encoder_predictor(sd, 32, x, ts, 256)
+    check("encoder predictor logits", logits.detach(), logits2, tol=1e-6)
+    grad2 = ref_cpu.encoder_predictor_cond_fn(sd, 32, 256, targets)(x, ts)
+    check("encoder predictor grad", grad, grad2, tol=1e-6)
+    print(f"  logits rms={logits.pow(2).mean().sqrt().item():.4f} grad rms={grad.pow(2).mean().sqrt().item():.3e}")
+    save("f10_encpred32", x_seed=71, ts=ts, targets=targets, logits=logits.detach(), grad=grad)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     if not only or "resblocks" in only:
@@ -304,4 +326,6 @@ if __name__ == "__main__":
         gen_vqvae()
     if not only or "classifier" in only:
         gen_classifier()
+    if not only or "encpred" in only:
+        gen_encpred()
     print("ok")

@@ -238,6 +238,27 @@ def classifier_cond_fn(sd: State, base: int, labels: Tensor, scale: float = 1.0)
     return cond_fn
 
 
+def encoder_predictor(sd: State, base: int, x: Tensor, ts: Tensor, rate: int, prefix: str = "") -> Tensor:
+    """EncoderPredictor.forward (models/encoder_predictor.py:43-58): [N,1,T] -> logits [N, num_latents, T // rate]."""
+    h = unet_predictor(sd, base, x, ts, prefix=prefix + "unet")
+    h = F.interpolate(h, size=(h.shape[-1] // rate,), mode="nearest")
+    return F.conv1d(h, sd[prefix + "out.weight"], sd[prefix + "out.bias"])
+
+
+def encoder_predictor_cond_fn(sd: State, base: int, rate: int, targets: Tensor, scale: float = 1.0) -> Callable:
+    """The cond_fn of VQVAE.decode(enc_pred=...) (vq_vae.py:125-130 with encoder_predictor.py:60-64)."""
+
+    def cond_fn(x, ts):
+        with torch.enable_grad():
+            xg = x.detach().clone().requires_grad_(True)
+            losses = F.cross_entropy(encoder_predictor(sd, base, xg, ts, rate), targets, reduction="none").mean(-1)
+            losses = losses * targets.shape[-1]
+            grads = torch.autograd.grad(losses.sum(), xg)[0]
+        return grads * scale * -1
+
+    return cond_fn
+
+
 # --------------------------------------------------------------------------
 # VQ (vq.py:98-143, 199-243)
 # --------------------------------------------------------------------------
@@ -372,10 +393,11 @@ def vqvae_decode(
     x_T: Tensor,
     noises: List[Tensor],
     constrain: bool = False,
+    cond_fn: Optional[Callable] = None,
 ) -> Tensor:
     cond = vq_embed(sd["vq.dictionary"], codes) if codes.dim() == 2 else codes
     return ddpm_sample(
         schedule, x_T,
         lambda xs, ts: unet_predictor(sd, base, xs, ts, cond=cond, labels=labels),
-        steps, noises, constrain=constrain,
+        steps, noises, constrain=constrain, cond_fn=cond_fn,
     )

@@ -4,8 +4,8 @@ Encode a clip with a VQ-VAE and decode it as another speaker, on MI355X.  Counte
 sample_vqvae.py (same flags and positionals; reference sample_vqvae.py:76-92): read 4 s of 16 kHz audio,
 `encode`, `decode(labels, constrain=True)`, clamp, write WAV; `--check-vq` re-encodes the result.
 Differences: WAV in/out directly (no ffmpeg); the model is put in eval mode (the reference's train-mode VQ
-bookkeeping crashes on current numpy; outputs are identical); `--enc-pred-path` needs the
-EncoderPredictor model, which is not built yet.
+bookkeeping crashes on current numpy; outputs are identical).  `--enc-pred-path` loads an
+EncoderPredictor whose guidance gradient comes from the library's explicit backward schedule (no autograd).
 """
 import argparse
 import os
@@ -14,7 +14,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from vq_voice_swap_amd import VQVAE  # noqa: E402
+from vq_voice_swap_amd import VQVAE, EncoderPredictor  # noqa: E402
 from vq_voice_swap_amd.audio import ChunkReader, ChunkWriter  # noqa: E402
 
 
@@ -39,8 +39,6 @@ def arg_parser():
 
 def main(argv=None):
     args = arg_parser().parse_args(argv)
-    if args.enc_pred_path:
-        raise SystemExit("encoder-predictor guidance needs the EncoderPredictor model (SURVEY.md 8f.1), which this build does not include yet")
     print("loading model from checkpoint...")
     model = VQVAE.load(args.checkpoint_path)
     assert args.label < model.num_labels
@@ -50,6 +48,12 @@ def main(argv=None):
     model.to(device)
     model.eval()
     model.set_precision(args.precision)
+    enc_pred = None
+    if args.enc_pred_path:  # reference sample_vqvae.py:24-28
+        print("loading encoder predictor")
+        enc_pred = EncoderPredictor.load(args.enc_pred_path).to(device)
+        enc_pred.eval()
+        enc_pred.set_precision(args.precision)
 
     print(f"loading waveform from {args.input_file}...")
     reader = ChunkReader(args.input_file, sample_rate=args.sample_rate, encoding=args.encoding)
@@ -65,7 +69,8 @@ def main(argv=None):
 
     print("decoding audio samples...")
     labels = torch.tensor([args.label]).long().to(device)
-    sample = model.decode(encoded, labels, steps=args.sample_steps, progress=True, constrain=True, seed=args.seed)
+    sample = model.decode(encoded, labels, steps=args.sample_steps, progress=True, constrain=True, seed=args.seed,
+                          enc_pred=enc_pred, enc_pred_scale=args.enc_pred_scale)
 
     if args.check_vq:
         assert not args.no_vq

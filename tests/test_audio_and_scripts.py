@@ -54,8 +54,9 @@ def test_import_shim_paths():
     from vq_voice_swap.models import Classifier, EncoderPredictor
     from vq_voice_swap.vq_vae import VQVAE  # noqa: F401
     assert Classifier(num_labels=3, base_channels=32).num_labels == 3
-    with pytest.raises(NotImplementedError):
-        EncoderPredictor(32, 256, 512)
+    ep = EncoderPredictor(32, 256, 512)
+    assert ep.save_kwargs() == dict(base_channels=32, downsample_rate=256, num_latents=512, bottleneck_dim=64)
+    assert "unet.up_blocks.34.post_cond.1.weight" in ep.state_dict() and tuple(ep.state_dict()["out.weight"].shape) == (512, 64, 1)
 
 
 @pytest.mark.gpu

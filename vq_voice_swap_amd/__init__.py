@@ -7,11 +7,12 @@ from .base import Savable, atomic_save
 from .classifier import Classifier
 from .diffusion import CosSchedule, Diffusion, ExpSchedule, Schedule, make_schedule, randn_clips
 from .diffusion_model import DiffusionModel
+from .encoder_predictor import EncoderPredictor
 from .unet import ResBlockModule, UNetEncoder, UNetPredictor
 from .vq import VQ
 from .vq_vae import VQVAE
 
 __all__ = [
     "Savable", "atomic_save", "CosSchedule", "Diffusion", "ExpSchedule", "Schedule", "make_schedule", "randn_clips",
-    "DiffusionModel", "Classifier", "ResBlockModule", "UNetEncoder", "UNetPredictor", "VQ", "VQVAE",
+    "DiffusionModel", "Classifier", "EncoderPredictor", "ResBlockModule", "UNetEncoder", "UNetPredictor", "VQ", "VQVAE",
 ]

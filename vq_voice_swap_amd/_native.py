@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VQVS_LIB_PATH") or os.path.join(_HERE, "libvqvs_hip.so")  # override: instrumented builds (tools/)
 CSRC = os.path.join(_HERE, "csrc")
 
-KIND_PREDICTOR, KIND_ENCODER, KIND_RESBLOCK, KIND_CLASSIFIER = 0, 1, 2, 3
+KIND_PREDICTOR, KIND_ENCODER, KIND_RESBLOCK, KIND_CLASSIFIER, KIND_ENCPRED = 0, 1, 2, 3, 4
 PREC_F32, PREC_BF16 = 0, 1
 DDPM_SIGMA_LARGE, DDPM_CONSTRAIN = 1, 2
 PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "float32": PREC_F32, "bf16": PREC_BF16, "bfloat16": PREC_BF16}
@@ -47,7 +47,7 @@ class Cfg(C.Structure):
 EXPORTS = [
     "vqvs_param_count", "vqvs_param_info", "vqvs_model_create", "vqvs_model_destroy", "vqvs_model_device_bytes",
     "vqvs_unet_forward", "vqvs_encoder_forward", "vqvs_resblock_forward", "vqvs_classifier_forward",
-    "vqvs_classifier_guidance", "vqvs_ddpm_step", "vqvs_ddpm_mean",
+    "vqvs_classifier_guidance", "vqvs_encpred_forward", "vqvs_encpred_guidance", "vqvs_ddpm_step", "vqvs_ddpm_mean",
     "vqvs_ddpm_guided_eps", "vqvs_randn", "vqvs_vq_argmin", "vqvs_vq_embed", "vqvs_debug_tap_count",
     "vqvs_debug_tap_info", "vqvs_debug_read_tap", "vqvs_forward_kernel_count", "vqvs_forward_model_bytes",
     "vqvs_forward_flops", "vqvs_set_profiling", "vqvs_op_info", "vqvs_op_desc", "vqvs_profile_read", "vqvs_last_error", "vqvs_version",
@@ -98,6 +98,8 @@ def lib():
     L.vqvs_resblock_forward.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     L.vqvs_classifier_forward.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     L.vqvs_classifier_guidance.argtypes = [vp, vp, vp, vp, f32, vp, vp, i32, i32, vp]
+    L.vqvs_encpred_forward.argtypes = [vp, vp, vp, vp, i32, i32, vp]
+    L.vqvs_encpred_guidance.argtypes = [vp, vp, vp, vp, f32, vp, vp, i32, i32, vp]
     L.vqvs_ddpm_step.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, u32, f32, u64, u64, u32, vp]
     L.vqvs_ddpm_mean.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp]
     L.vqvs_ddpm_guided_eps.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, u32, vp]

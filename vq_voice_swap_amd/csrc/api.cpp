@@ -194,6 +194,39 @@ int vqvs_classifier_guidance(vqvs_model* m, const float* d_x, const float* d_ts,
   return run_model(m, c);
 }
 
+int vqvs_encpred_forward(vqvs_model* m, const float* d_x, const float* d_ts, float* d_logits, int B, int T, void* stream) {
+  if (int e = check_run(m, VQVS_KIND_ENCPRED, B, T)) return e;
+  if (!d_x || !d_ts || !d_logits) VQVS_FAIL(VQVS_ERR_ARG, "x, ts and logits must be non-NULL");
+  if (T % m->cfg.reserved[1]) VQVS_FAIL(VQVS_ERR_ARG, "T=%d is not a multiple of the downsample rate %d", T, m->cfg.reserved[1]);
+  RunCtx c;
+  c.B = B;
+  c.Lbase = T;
+  c.x = d_x;
+  c.ts = d_ts;
+  c.out = d_logits;
+  c.st = reinterpret_cast<hipStream_t>(stream);
+  return run_model(m, c);
+}
+
+int vqvs_encpred_guidance(vqvs_model* m, const float* d_x, const float* d_ts, const int64_t* d_targets, float scale, float* d_grad,
+                          float* d_logits, int B, int T, void* stream) {
+  if (int e = check_run(m, VQVS_KIND_ENCPRED, B, T)) return e;
+  if (!d_x || !d_ts || !d_targets || !d_grad) VQVS_FAIL(VQVS_ERR_ARG, "x, ts, targets and grad must be non-NULL");
+  if (T % m->cfg.reserved[1]) VQVS_FAIL(VQVS_ERR_ARG, "T=%d is not a multiple of the downsample rate %d", T, m->cfg.reserved[1]);
+  RunCtx c;
+  c.B = B;
+  c.Lbase = T;
+  c.x = d_x;
+  c.ts = d_ts;
+  c.labels = d_targets;  // the head reads them as targets; the UNet itself is label-free
+  c.out = d_logits;
+  c.backward = true;
+  c.gscale = scale;
+  c.grad_out = d_grad;
+  c.st = reinterpret_cast<hipStream_t>(stream);
+  return run_model(m, c);
+}
+
 int vqvs_ddpm_step(const float* d_x_t, const float* d_eps, const float* d_noise, const float* d_alpha_t, const float* d_alpha_prev,
                    float* d_x_prev, int B, int T, uint32_t flags, float noise_scale, uint64_t seed, uint64_t clip_offset,
                    uint32_t step_index, void* stream) {

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void bw_act_kernel(const BwActArgs a) {
   const int c = oct * 8;
   f32x8 sc, sh;
   {
-    const float2* p = a.ss + (size_t)b * a.C + c;
+    const float2* p = a.ss + (size_t)b * a.ss_stride + a.ss_c0 + c;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float2 q = p[j];
@@ -46,27 +46,29 @@ __global__ __launch_bounds__(256) void bw_act_kernel(const BwActArgs a) {
       sh[j] = q.y;
     }
   }
-  const int Lt = a.up ? (a.L >> 1) : a.L;
-  const T* tb = reinterpret_cast<const T*>(a.t) + (size_t)b * Lt * a.C + c;
+  const int Lt = a.resize == BW_FROM_HALF ? (a.L >> 1) : (a.resize == BW_FROM_DOUBLE ? 2 * a.L : a.L);
+  const T* tb = reinterpret_cast<const T*>(a.t) + (size_t)b * Lt * a.t_C + a.t_c0 + c;
   const T* xb = reinterpret_cast<const T*>(a.xf) + (size_t)b * a.L * a.C + c;
-  T* ob = reinterpret_cast<T*>(a.du) + (size_t)b * a.L * a.C + c;
+  T* ob = reinterpret_cast<T*>(a.du) + (size_t)b * a.L * a.du_C + a.du_c0 + c;
   f32x8 s1 = f32x8_zero(), s2 = f32x8_zero();
-  const float gsc = a.up ? 0.5f : 1.0f;
   if (r0 < rpp) {
     for (int r = r0; r < STAT_TILE; r += rpp) {
       const int t = t0 + r;
       if (t >= a.L) break;
-      const f32x8 g = Elem<T>::load8(tb + (size_t)(a.up ? (t >> 1) : t) * a.C);
+      f32x8 g;
+      if (a.resize == BW_FROM_HALF) g = Elem<T>::load8(tb + (size_t)(t >> 1) * a.t_C) * 0.5f;
+      else if (a.resize == BW_FROM_DOUBLE) g = Elem<T>::load8(tb + (size_t)(2 * t) * a.t_C) + Elem<T>::load8(tb + (size_t)(2 * t + 1) * a.t_C);
+      else g = Elem<T>::load8(tb + (size_t)t * a.t_C);
       const f32x8 x = Elem<T>::load8(xb + (size_t)t * a.C);
       f32x8 du;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float u = fmaf(x[j], sc[j], sh[j]);
-        du[j] = g[j] * gsc * gelu_grad_f(u);
+        du[j] = g[j] * gelu_grad_f(u);
         s1[j] += du[j];
         s2[j] = fmaf(du[j], u, s2[j]);
       }
-      Elem<T>::store8(ob + (size_t)t * a.C, du);
+      Elem<T>::store8(ob + (size_t)t * a.du_C, du);
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(256) void bw_act_kernel(const BwActArgs a) {
       q1 += red[(g * a.C + cc) * 2 + 0];
       q2 += red[(g * a.C + cc) * 2 + 1];
     }
-    float* o = a.partials + (((size_t)b * gridDim.x + blockIdx.x) * a.C + cc) * 2;
+    float* o = a.partials + (((size_t)b * gridDim.x + blockIdx.x) * a.part_C + a.part_c0 + cc) * 2;
     o[0] = q1;
     o[1] = q2;
   }
@@ -161,9 +163,9 @@ __global__ __launch_bounds__(256) void bw_affine_kernel(const BwAffineArgs a) {
   const long long item = (long long)blockIdx.x * 256 + threadIdx.x;
   if (item >= (long long)a.L * opr) return;
   const int t = (int)(item / opr), c = (int)(item % opr) * 8;
-  const float4* cf = a.coef + (size_t)b * a.C + c;
+  const float4* cf = a.coef + (size_t)b * a.coef_stride + a.coef_c0 + c;
   const size_t idx = ((size_t)b * a.L + t) * a.C + c;
-  const f32x8 du = Elem<T>::load8(reinterpret_cast<const T*>(a.du) + idx);
+  const f32x8 du = Elem<T>::load8(reinterpret_cast<const T*>(a.du) + ((size_t)b * a.L + t) * a.du_C + a.du_c0 + c);
   const f32x8 x = Elem<T>::load8(reinterpret_cast<const T*>(a.xf) + idx);
   f32x8 v;
 #pragma unroll
@@ -172,13 +174,80 @@ __global__ __launch_bounds__(256) void bw_affine_kernel(const BwAffineArgs a) {
     v[j] = fmaf(q.x, du[j], fmaf(q.y, x[j], q.z));
   }
   if (a.skip) {
-    if (a.skip_half)
-      v += Elem<T>::load8(reinterpret_cast<const T*>(a.skip) + ((size_t)b * (a.L >> 1) + (t >> 1)) * a.C + c) * 0.5f;
+    const T* sk = reinterpret_cast<const T*>(a.skip);
+    if (a.skip_mode == BW_FROM_HALF)
+      v += Elem<T>::load8(sk + ((size_t)b * (a.L >> 1) + (t >> 1)) * a.C + c) * 0.5f;
+    else if (a.skip_mode == BW_FROM_DOUBLE)
+      v += Elem<T>::load8(sk + ((size_t)b * (2 * a.L) + 2 * t) * a.C + c) + Elem<T>::load8(sk + ((size_t)b * (2 * a.L) + 2 * t + 1) * a.C + c);
     else
-      v += Elem<T>::load8(reinterpret_cast<const T*>(a.skip) + idx);
+      v += Elem<T>::load8(sk + idx);
   }
-  if (a.extra) v += Elem<T>::load8(reinterpret_cast<const T*>(a.extra) + idx);
+  if (a.extra) v += Elem<T>::load8(reinterpret_cast<const T*>(a.extra) + ((size_t)b * a.L + t) * a.extra_C + a.extra_c0 + c);
   Elem<T>::store8(reinterpret_cast<T*>(a.out) + idx, v);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bw_add_kernel(const T* x, const T* y, T* out, long long n8) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  Elem<T>::store8(out + i * 8, Elem<T>::load8(x + i * 8) + Elem<T>::load8(y + i * 8));
+}
+
+// ------------------------------------------------------------------------------------
+// EncoderPredictor head: one workgroup = 64 latent positions of one clip.  lane = position, wave = logit / channel slice.
+// ------------------------------------------------------------------------------------
+constexpr int EH_POS = 64;
+template <typename T>
+__global__ __launch_bounds__(256) void enc_head_kernel(const EncHeadArgs a) {
+  extern __shared__ float ehs[];
+  float* rows = ehs;                      // [EH_POS][Cb + 1]
+  float* lg = rows + EH_POS * (a.Cb + 1);  // [D][EH_POS]
+  float* red = lg + (size_t)a.D * EH_POS;  // [4][EH_POS]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int b = blockIdx.y, i0 = blockIdx.x * EH_POS;
+  const int npos = min(EH_POS, a.T1 - i0);
+  for (int k = tid; k < EH_POS * a.Cb; k += 256) {
+    const int p = k / a.Cb, c = k - p * a.Cb;
+    rows[p * (a.Cb + 1) + c] = p < npos ? a.o[((size_t)b * a.T + (size_t)(i0 + p) * a.rate) * a.Cb + c] : 0.f;
+  }
+  __syncthreads();
+  const float* row = rows + lane * (a.Cb + 1);
+  for (int d = wv; d < a.D; d += 4) {
+    const float* w = a.w + (size_t)d * a.Cb;  // wave-uniform
+    float acc = a.bias[d];
+    for (int c = 0; c < a.Cb; ++c) acc = fmaf(w[c], row[c], acc);
+    lg[d * EH_POS + lane] = acc;
+    if (a.logits && lane < npos) a.logits[((size_t)b * a.D + d) * a.T1 + i0 + lane] = acc;
+  }
+  if (!a.targets) return;
+  __syncthreads();
+  // softmax over the D logits of each position: every wave reduces its slice, then the four slices are combined
+  float m = -3.0e38f;
+  for (int d = wv; d < a.D; d += 4) m = fmaxf(m, lg[d * EH_POS + lane]);
+  red[wv * EH_POS + lane] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[lane], red[EH_POS + lane]), fmaxf(red[2 * EH_POS + lane], red[3 * EH_POS + lane]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int d = wv; d < a.D; d += 4) sum += __expf(lg[d * EH_POS + lane] - m);
+  red[wv * EH_POS + lane] = sum;
+  __syncthreads();
+  sum = (red[lane] + red[EH_POS + lane]) + (red[2 * EH_POS + lane] + red[3 * EH_POS + lane]);
+  const float inv = 1.0f / sum;
+  long long y = lane < npos ? a.targets[(size_t)b * a.T1 + i0 + lane] : 0;
+  if (y < 0) y = 0;
+  if (y >= a.D) y = a.D - 1;
+  // d(-gscale * CE)/dlogit = gscale * (onehot - softmax)
+  for (int d = wv; d < a.D; d += 4) lg[d * EH_POS + lane] = a.gscale * ((d == (int)y ? 1.0f : 0.0f) - __expf(lg[d * EH_POS + lane] - m) * inv);
+  __syncthreads();
+  if (lane < npos) {
+    T* out = reinterpret_cast<T*>(a.dO) + ((size_t)b * a.T + (size_t)(i0 + lane) * a.rate) * a.Cb;
+    for (int c = wv; c < a.Cb; c += 4) {
+      float acc = 0.f;
+      for (int d = 0; d < a.D; ++d) acc = fmaf(a.w[(size_t)d * a.Cb + c], lg[d * EH_POS + lane], acc);
+      out[c] = (T)acc;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------
@@ -493,7 +562,7 @@ size_t head_lds_floats(const HeadArgs& a) {
 int launch_bw_act(const BwActArgs& a, int B, int precision, hipStream_t st) {
   const int opr = a.C / 8;
   if (a.C % 8 || opr > 256 || 256 % opr) VQVS_FAIL(-1, "bw_act: unsupported C=%d", a.C);
-  if (a.up && (a.L & 1)) VQVS_FAIL(-1, "bw_act: avg-pool backward needs an even length");
+  if (a.resize == BW_FROM_HALF && (a.L & 1)) VQVS_FAIL(-1, "bw_act: avg-pool backward needs an even length");
   dim3 grid((a.L + STAT_TILE - 1) / STAT_TILE, B);
   if (precision == 0)
     hipLaunchKernelGGL(bw_act_kernel<float>, grid, dim3(256), 0, st, a);
@@ -530,6 +599,41 @@ int launch_in_conv_bw(const InConvBwArgs& a, int B, int precision, hipStream_t s
     hipLaunchKernelGGL(in_conv_bw_kernel<float>, grid, dim3(256), 0, st, a);
   else
     hipLaunchKernelGGL(in_conv_bw_kernel<bf16_t>, grid, dim3(256), 0, st, a);
+  VQVS_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_bw_add(const void* x, const void* y, void* out, long long n, int precision, hipStream_t st) {
+  if (n % 8) VQVS_FAIL(-1, "bw_add: element count must be a multiple of 8");
+  const long long n8 = n / 8;
+  dim3 grid((unsigned)((n8 + 255) / 256));
+  if (precision == 0)
+    hipLaunchKernelGGL(bw_add_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)y, (float*)out, n8);
+  else
+    hipLaunchKernelGGL(bw_add_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)y, (bf16_t*)out, n8);
+  VQVS_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_enc_head(const EncHeadArgs& a, int B, int precision, hipStream_t st) {
+  const size_t lds = ((size_t)EH_POS * (a.Cb + 1) + (size_t)a.D * EH_POS + 4 * EH_POS) * 4;
+  if (lds > 150 * 1024) VQVS_FAIL(-1, "encoder-predictor head: num_latents=%d needs %zu bytes of LDS (max 150 KB)", a.D, lds);
+  if (a.T1 * a.rate != a.T) VQVS_FAIL(-1, "encoder-predictor head: T=%d is not %d x %d", a.T, a.T1, a.rate);
+  dim3 grid((a.T1 + EH_POS - 1) / EH_POS, B);
+  static bool attr_done[2] = {false, false};
+  if (precision == 0) {
+    if (!attr_done[0]) {
+      VQVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_head_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      attr_done[0] = true;
+    }
+    hipLaunchKernelGGL(enc_head_kernel<float>, grid, dim3(256), lds, st, a);
+  } else {
+    if (!attr_done[1]) {
+      VQVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_head_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      attr_done[1] = true;
+    }
+    hipLaunchKernelGGL(enc_head_kernel<bf16_t>, grid, dim3(256), lds, st, a);
+  }
   VQVS_HIP(hipGetLastError());
   return 0;
 }

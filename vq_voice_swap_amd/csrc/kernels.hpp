@@ -147,13 +147,17 @@ int launch_xform(const XformArgs& a, int B, int precision, hipStream_t st);
 // The two transposed convolutions of a block run on the forward MFMA kernel with transposed, tap-flipped
 // weights; the kernels below are the element-wise pieces in between.
 // ----------------------------------------------------------------------------------
+enum { BW_SAME = 0, BW_FROM_HALF = 1, BW_FROM_DOUBLE = 2 };  // resolution of an incoming gradient relative to the output rows
 struct BwActArgs {  // du = resize^T(t) * gelu'(u), u = xf*scale + shift;  partial sums (sum du, sum du*u) per tile
-  const void* t;     // gradient w.r.t. the activation output: [B][L][C], or [B][L/2][C] when up (avg-pool backward)
+  const void* t;     // gradient w.r.t. the activation output; rows of t_C channels, this tensor's slice starts at t_c0.
+                     // BW_SAME: [B][L]; BW_FROM_HALF: [B][L/2], enters as 0.5*t[r>>1] (avg-pool backward);
+                     // BW_FROM_DOUBLE: [B][2L], enters as t[2r] + t[2r+1] (nearest-upsampling backward)
   const void* xf;    // forward tensor the GroupNorm read: [B][L][C]
-  const float2* ss;  // [B][C] forward (scale, shift)
-  void* du;          // out [B][L][C] (may alias t when !up)
-  float* partials;   // [B][ntiles][C][2], tiles of STAT_TILE rows
-  int C, L, up;
+  const float2* ss;  // forward (scale, shift): row b at ss + b*ss_stride + ss_c0
+  void* du;          // out rows of du_C channels, slice at du_c0 (may alias t when BW_SAME)
+  float* partials;   // [B][ntiles][part_C][2] at column part_c0, tiles of STAT_TILE rows
+  int C, L, resize;
+  int t_C, t_c0, du_C, du_c0, ss_stride, ss_c0, part_C, part_c0;
 };
 int launch_bw_act(const BwActArgs& a, int B, int precision, hipStream_t st);
 
@@ -168,16 +172,18 @@ struct GnBwArgs {  // GroupNorm backward coefficients: dx = P*du + Q*x + R  per 
 int launch_gn_bw(const GnBwArgs& a, int B, hipStream_t st);
 
 struct BwAffineArgs {  // out = P*du + Q*xf + R (+ skip gradient) (+ extra)
-  const void* du;
-  const void* xf;
-  const float4* coef;
-  const void* skip;   // gradient arriving over the identity skip, or nullptr
-  int skip_half;      // 1: skip is [B][L/2][C] and enters as 0.5*skip[t>>1] (avg-pool backward)
-  const void* extra;  // second same-shape addend (gradient through the 1x1 skip convolution), or nullptr
-  void* out;          // [B][L][C] (may alias du)
+  const void* du;     // rows of du_C channels, slice at du_c0
+  const void* xf;     // [B][L][C]
+  const float4* coef; // row b at coef + b*coef_stride + coef_c0
+  const void* skip;   // gradient arriving over the identity skip ([B][.][C]), or nullptr
+  int skip_mode;      // BW_SAME / BW_FROM_HALF (0.5*skip[r>>1]) / BW_FROM_DOUBLE (skip[2r] + skip[2r+1])
+  const void* extra;  // second addend (gradient through the 1x1 skip convolution): rows of extra_C channels, slice at extra_c0
+  void* out;          // [B][L][C] (may alias du when du_C == C)
   int C, L;
+  int du_C, du_c0, coef_stride, coef_c0, extra_C, extra_c0;
 };
 int launch_bw_affine(const BwAffineArgs& a, int B, int precision, hipStream_t st);
+int launch_bw_add(const void* a, const void* b, void* out, long long n, int precision, hipStream_t st);  // out = a + b (n multiple of 8)
 
 struct InConvBwArgs {  // dx[b][t] = sum_k sum_c w[c][k] * dh[b][t-k+1][c]   (backward of unet.py:137 in_conv, Cin = 1)
   const void* dh;   // [B][T][C]
@@ -210,6 +216,21 @@ struct HeadArgs {
   void* dh;            // [B][L][C] out (gradient), when labels
 };
 int launch_cls_head(const HeadArgs& a, int B, int precision, hipStream_t st);
+
+// EncoderPredictor head (encoder_predictor.py:53-58, 60-64; vq_vae.py:125-130): nearest down-sampling of the UNet
+// output by `rate`, 1x1 convolution to `D` logits per latent position, and -- with targets -- the gradient of
+// -gscale * sum of cross-entropies with respect to the UNet output (non-zero only at the sampled rows).
+struct EncHeadArgs {
+  const float* o;      // [B][T][Cb] UNet output (float32, channels-last)
+  const float* w;      // [D][Cb]
+  const float* bias;   // [D]
+  float* logits;       // [B][D][T1] (the reference's NCT layout) or nullptr
+  const int64_t* targets;  // [B][T1] or nullptr = forward only
+  float gscale;
+  void* dO;            // [B][T][Cb] of T: rows i*rate receive the gradient (the tensor is zeroed by the caller)
+  int Cb, D, T, T1, rate;
+};
+int launch_enc_head(const EncHeadArgs& a, int B, int precision, hipStream_t st);
 
 // layout changes at the library boundary (reference tensors are NCT float32)
 int launch_nct_to_ntc(const float* in, void* out, float* stats, int B, int C, int L, int ntiles, int precision, hipStream_t st);

@@ -222,7 +222,7 @@ class Builder {
   // what the backward pass needs to know about one forward ResBlock
   struct BlockRec {
     BlockSpec s;
-    TensorH x, h1, out;
+    TensorH x, x2, h1, out;  // x2: the skip-stack tensor of a concatenating block (id < 0 otherwise)
     size_t ss1 = 0, ss2 = 0, mr1 = 0, mr2 = 0;
   };
   size_t alloc_ss(int C) {
@@ -461,15 +461,20 @@ class Builder {
       if (pre_xform) release(g2);
     }
     release(h1);
-    if (rec) *rec = BlockRec{s, ins[0], h1, out, ss1, ss2, mr1, mr2};
+    if (rec) *rec = BlockRec{s, ins[0], ins.size() > 1 ? ins[1] : TensorH{}, h1, out, ss1, ss2, mr1, mr2};
     return out;
   }
 
   // ---- backward pieces (classifier guidance) ------------------------------------------------------
-  void add_bw_act(const TensorH& t, bool up, const TensorH& xf, size_t ss_off, const TensorH& du, size_t part_off) {
+  // slice [c0, c0 + xf.C) of the (possibly wider) gradient tensor `t` / output `du`; statistics into columns
+  // [c0, c0 + xf.C) of a partials block that is Ctot channels wide
+  void add_bw_act(const TensorH& t, int resize, const TensorH& xf, size_t ss_off, const TensorH& du, size_t part_off, int c0 = 0,
+                  int Ctot = 0) {
     Builder* self = this;
     const int prec = m_->cfg.precision;
-    m_->meta.push_back({"bw_act", "C=" + std::to_string(xf.C) + " L>>" + std::to_string(xf.lshift) + (up ? " ^" : ""),
+    if (Ctot == 0) Ctot = xf.C;
+    m_->meta.push_back({"bw_act", "C=" + std::to_string(xf.C) + " L>>" + std::to_string(xf.lshift) +
+                                      (resize == BW_FROM_HALF ? " from L/2" : resize == BW_FROM_DOUBLE ? " from 2L" : ""),
                         xf.C * (2 * lscale(xf.lshift) + lscale(t.lshift)), 0, 0});
     m_->add_op([=](const RunCtx& c) -> int {
       BwActArgs a{};
@@ -480,7 +485,15 @@ class Builder {
       a.partials = self->statp(part_off);
       a.C = xf.C;
       a.L = shiftL(c.Lbase, xf.lshift);
-      a.up = up ? 1 : 0;
+      a.resize = resize;
+      a.t_C = t.C;
+      a.t_c0 = t.C == xf.C ? 0 : c0;
+      a.du_C = du.C;
+      a.du_c0 = du.C == xf.C ? 0 : c0;
+      a.ss_stride = Ctot;
+      a.ss_c0 = c0;
+      a.part_C = Ctot;
+      a.part_c0 = c0;
       return launch_bw_act(a, c.B, prec, c.st);
     });
   }
@@ -504,10 +517,12 @@ class Builder {
     });
     return coef;
   }
-  void add_bw_affine(const TensorH& du, const TensorH& xf, size_t coef, const TensorH* skip, bool skip_half, const TensorH* extra,
-                     const TensorH& out) {
+  // out = P*du + Q*xf + R (+ skip) (+ extra); du / extra / coef may be slices [c0, c0 + xf.C) of Ctot-wide buffers
+  void add_bw_affine(const TensorH& du, const TensorH& xf, size_t coef, const TensorH* skip, int skip_mode, const TensorH* extra,
+                     const TensorH& out, int c0 = 0, int Ctot = 0) {
     Builder* self = this;
     const int prec = m_->cfg.precision;
+    if (Ctot == 0) Ctot = xf.C;
     const bool has_skip = skip != nullptr, has_extra = extra != nullptr;
     const TensorH K = skip ? *skip : TensorH{}, E = extra ? *extra : TensorH{};
     m_->meta.push_back({"bw_affine", "C=" + std::to_string(xf.C) + " L>>" + std::to_string(xf.lshift),
@@ -518,12 +533,27 @@ class Builder {
       a.xf = self->act(xf.off);
       a.coef = reinterpret_cast<const float4*>(self->miscp(coef));
       a.skip = has_skip ? self->act(K.off) : nullptr;
-      a.skip_half = skip_half ? 1 : 0;
+      a.skip_mode = skip_mode;
       a.extra = has_extra ? self->act(E.off) : nullptr;
       a.out = self->act(out.off);
       a.C = xf.C;
       a.L = shiftL(c.Lbase, xf.lshift);
+      a.du_C = du.C;
+      a.du_c0 = du.C == xf.C ? 0 : c0;
+      a.coef_stride = Ctot;
+      a.coef_c0 = c0;
+      a.extra_C = has_extra ? E.C : 0;
+      a.extra_c0 = has_extra && E.C != xf.C ? c0 : 0;
       return launch_bw_affine(a, c.B, prec, c.st);
+    });
+  }
+  void add_bw_add(const TensorH& x, const TensorH& y, const TensorH& out) {  // out = x + y (same shape)
+    Builder* self = this;
+    const int prec = m_->cfg.precision;
+    m_->meta.push_back({"bw_add", "C=" + std::to_string(x.C) + " L>>" + std::to_string(x.lshift), 3 * x.C * lscale(x.lshift), 0, 0});
+    m_->add_op([=](const RunCtx& c) -> int {
+      const long long n = (long long)c.B * shiftL(c.Lbase, x.lshift) * x.C;
+      return launch_bw_add(self->act(x.off), self->act(y.off), self->act(out.off), n, prec, c.st);
     });
   }
   // plain convolution of a raw tensor with transposed weights (no prologue, no statistics, zero bias)
@@ -535,42 +565,70 @@ class Builder {
     add_conv({g}, pk, std::vector<float>(Cin_fwd, 0.f), Cin_fwd, out, nullptr, 0);
   }
 
-  // Gradient of one ResBlock with respect to its input (no concatenation, resize none / avg-pool):
+  // Gradient of one ResBlock with respect to its input(s):
   //   out = skip(resize(x)) + conv2(gelu(GN2(conv1(resize(gelu(GN1(x)))))))       (unet.py:307-316)
-  // consumes `dout` (released) and returns dx.
-  TensorH resblock_backward(const BlockRec& r, const TensorH& dout) {
+  // x may be the concatenation [x, x2] (up path, unet.py:156).  Consumes `dout` (released); returns dx and sets
+  // *dx2 to the gradient of the second input when the block concatenates.
+  TensorH resblock_backward(const BlockRec& r, const TensorH& dout, TensorH* dx2 = nullptr) {
     const BlockSpec& s = r.s;
-    const std::string pre = s.prefix + ".";
+    const std::string pre = s.prefix.empty() ? "" : s.prefix + ".";
     const int cin = s.cin, cout = s.cout;
     const int in_shift = r.x.lshift, out_shift = r.out.lshift;
-    const bool down = s.resize == RESIZE_AVG2;
+    const bool cat = r.x2.id >= 0;
+    // gradient at the input resolution from a tensor at the output resolution
+    const int rs = s.resize == RESIZE_AVG2 ? BW_FROM_HALF : (s.resize == RESIZE_UP2 ? BW_FROM_DOUBLE : BW_SAME);
     // d gelu2 = conv2^T(dout);  du2 = . * gelu'(u2);  d h1 = GN2 backward
     TensorH t1 = new_tensor(cout, out_shift, false, false);
     const std::string c2 = pre + (cfg_dropout(m_->cfg) ? "post_cond.2" : "post_cond.1");
     add_conv_t(dout, P(c2 + ".weight"), cout, cout, 3, s.dil, t1);
     const size_t pa = alloc_stats(cout, out_shift);
-    add_bw_act(t1, false, r.h1, r.ss2, t1, pa);
+    add_bw_act(t1, BW_SAME, r.h1, r.ss2, t1, pa);
     const size_t cf2 = add_gn_bw(cout, out_shift, pa, r.ss2, r.mr2);
-    add_bw_affine(t1, r.h1, cf2, nullptr, false, nullptr, t1);
+    add_bw_affine(t1, r.h1, cf2, nullptr, BW_SAME, nullptr, t1);
     // d resize(gelu1) = conv1^T(d h1);  du1 = resize^T(.) * gelu'(u1);  dx = GN1 backward + skip path
     TensorH t2 = new_tensor(cin, out_shift, false, false);
     add_conv_t(t1, P(pre + "pre_cond.2.weight"), cout, cin, 3, 1, t2);
     release(t1);
-    TensorH du1 = down ? new_tensor(cin, in_shift, false, false) : t2;
     const size_t pb = alloc_stats(cin, in_shift);
-    add_bw_act(t2, down, r.x, r.ss1, du1, pb);
-    if (down) release(t2);
-    const size_t cf1 = add_gn_bw(cin, in_shift, pb, r.ss1, r.mr1);
-    if (cin != cout) {
-      TensorH t3 = new_tensor(cin, out_shift, false, false);
-      add_conv_t(dout, P(pre + "skip.1.weight"), cout, cin, 1, 1, t3);
-      add_bw_affine(du1, r.x, cf1, nullptr, false, &t3, du1);
-      release(t3);
-    } else {
-      add_bw_affine(du1, r.x, cf1, &dout, down, nullptr, du1);
+    if (!cat) {
+      TensorH du1 = rs != BW_SAME ? new_tensor(cin, in_shift, false, false) : t2;
+      add_bw_act(t2, rs, r.x, r.ss1, du1, pb);
+      if (rs != BW_SAME) release(t2);
+      const size_t cf1 = add_gn_bw(cin, in_shift, pb, r.ss1, r.mr1);
+      if (cin != cout) {
+        TensorH t3 = new_tensor(cin, out_shift, false, false);
+        add_conv_t(dout, P(pre + "skip.1.weight"), cout, cin, 1, 1, t3);
+        add_bw_affine(du1, r.x, cf1, nullptr, BW_SAME, &t3, du1);
+        release(t3);
+      } else {
+        add_bw_affine(du1, r.x, cf1, &dout, rs, nullptr, du1);
+      }
+      release(dout);
+      return du1;
     }
+    // concatenated input (never resized, always a 1x1 skip convolution): t2 and t3 are cin wide, the two sources
+    // take their column slices; GroupNorm 1 runs over the concatenation
+    const TensorH srcs[2] = {r.x, r.x2};
+    int c0 = 0;
+    for (int i = 0; i < 2; ++i) {
+      add_bw_act(t2, BW_SAME, srcs[i], r.ss1, t2, pb, c0, cin);
+      c0 += srcs[i].C;
+    }
+    const size_t cf1 = add_gn_bw(cin, in_shift, pb, r.ss1, r.mr1);
+    TensorH t3 = new_tensor(cin, out_shift, false, false);
+    add_conv_t(dout, P(pre + "skip.1.weight"), cout, cin, 1, 1, t3);
     release(dout);
-    return du1;
+    TensorH outs[2];
+    c0 = 0;
+    for (int i = 0; i < 2; ++i) {
+      outs[i] = new_tensor(srcs[i].C, in_shift, false, false);
+      add_bw_affine(t2, srcs[i], cf1, nullptr, BW_SAME, &t3, outs[i], c0, cin);
+      c0 += srcs[i].C;
+    }
+    release(t2);
+    release(t3);
+    if (dx2) *dx2 = outs[1];
+    return outs[0];
   }
 
   void tap(const std::string& name, const TensorH& t) { m_->taps.push_back({name, t}); }
@@ -633,7 +691,7 @@ int enumerate_params(const vqvs_cfg& c, std::vector<ParamDef>& out) {
   out.clear();
   const int base = c.base_channels;
   const bool drop = cfg_dropout(c);
-  if (c.kind == VQVS_KIND_PREDICTOR) {
+  if (c.kind == VQVS_KIND_PREDICTOR || c.kind == VQVS_KIND_ENCPRED) {
     const int E = 4 * base;
     out.push_back({"time_embed.proj.weight", {E, E}});
     out.push_back({"time_embed.proj.bias", {E}});
@@ -655,6 +713,11 @@ int enumerate_params(const vqvs_cfg& c, std::vector<ParamDef>& out) {
     out.push_back({"out.0.0.bias", {base}});
     out.push_back({"out.1.weight", {c.out_channels, base, 3}});
     out.push_back({"out.1.bias", {c.out_channels}});
+    if (c.kind == VQVS_KIND_ENCPRED) {  // encoder_predictor.py:40-41: self.unet = UNetPredictor(...), self.out = Conv1d(bottleneck, latents, 1)
+      for (auto& d : out) d.name = "unet." + d.name;
+      out.push_back({"out.weight", {c.reserved[2], c.out_channels, 1}});
+      out.push_back({"out.bias", {c.reserved[2]}});
+    }
   } else if (c.kind == VQVS_KIND_ENCODER) {
     out.push_back({"in_conv.weight", {base, c.in_channels, 3}});
     out.push_back({"in_conv.bias", {base}});
@@ -711,6 +774,12 @@ static int check_cfg(const vqvs_cfg& c) {
   if (c.kind == VQVS_KIND_PREDICTOR) {
     if (c.out_channels != 1 && (c.out_channels % 32)) VQVS_FAIL(VQVS_ERR_ARG, "out_channels must be 1 or a multiple of 32");
     if (c.cond_channels % 32) VQVS_FAIL(VQVS_ERR_ARG, "cond_channels must be a multiple of 32");
+  } else if (c.kind == VQVS_KIND_ENCPRED) {
+    if (c.out_channels % 32 || c.out_channels < 32 || c.out_channels > 256) VQVS_FAIL(VQVS_ERR_ARG, "bottleneck_dim must be a multiple of 32 in 32..256");
+    if (c.cond_channels) VQVS_FAIL(VQVS_ERR_ARG, "the encoder predictor's UNet is unconditional");
+    if (c.num_labels) VQVS_FAIL(VQVS_ERR_ARG, "the encoder predictor's UNet has no class embedding");
+    if (c.reserved[2] < 1) VQVS_FAIL(VQVS_ERR_ARG, "num_latents (reserved[2]) must be positive");
+    if (c.reserved[1] < 1 || c.max_T % c.reserved[1]) VQVS_FAIL(VQVS_ERR_ARG, "downsample_rate %d must divide max_T", c.reserved[1]);
   } else if (c.kind == VQVS_KIND_CLASSIFIER) {
     if (c.num_labels < 1 || c.num_labels > 8192) VQVS_FAIL(VQVS_ERR_ARG, "classifier num_labels must be in 1..8192 (got %d)", c.num_labels);
     if (c.max_T % 512) VQVS_FAIL(VQVS_ERR_ARG, "classifier max_T must be a multiple of 512 (got %d)", c.max_T);
@@ -764,18 +833,25 @@ int build_model(vqvs_model* m, const float* const* hp) {
       return launch_ntc_to_nct(bp->act(y.off), r.out, r.B, Cout, shiftL(r.Lbase, y.lshift), prec, r.st);
     });
     b.tap("out", y);
-  } else if (c.kind == VQVS_KIND_PREDICTOR) {
+  } else if (c.kind == VQVS_KIND_PREDICTOR || c.kind == VQVS_KIND_ENCPRED) {
+    // ENCPRED (encoder_predictor.py:25-58): the same UNet under the "unet." prefix with a bottleneck output, every
+    // intermediate kept resident for the backward schedule appended below
+    const bool encpred = c.kind == VQVS_KIND_ENCPRED;
+    const std::string px = encpred ? "unet." : "";
+    b.persist = encpred;
     const int E = 4 * base;
     std::vector<BlockSpec> d, mdl, u;
     predictor_blocks(base, d, mdl, u);
+    for (auto* v : {&d, &mdl, &u})
+      for (auto& sp : *v) sp.prefix = px + sp.prefix;
     // ---- embedding + all blocks' FiLM rows
     std::vector<float> freqs(E / 2);
     for (int i = 0; i < E / 2; ++i)  // wavegrad.py:361-369 (float32 tensor math)
       freqs[i] = (float)(std::exp((double)(float)(-std::log(100.0 / 0.1)) * (double)i / (double)(E / 2 - 1))) * 100.0f;
     const size_t freq_off = b.blob.add(freqs.data(), freqs.size() * 4);
-    const size_t w1 = b.blob_f32_transposed(b.P("time_embed.proj.weight"), E, E), b1 = b.blob_f32("time_embed.proj.bias");
-    const size_t w2 = b.blob_f32_transposed(b.P("time_embed_extra.1.weight"), E, E), b2 = b.blob_f32("time_embed_extra.1.bias");
-    const size_t ce = c.num_labels > 0 ? b.blob_f32("class_embed.weight") : 0;
+    const size_t w1 = b.blob_f32_transposed(b.P(px + "time_embed.proj.weight"), E, E), b1 = b.blob_f32(px + "time_embed.proj.bias");
+    const size_t w2 = b.blob_f32_transposed(b.P(px + "time_embed_extra.1.weight"), E, E), b2 = b.blob_f32(px + "time_embed_extra.1.bias");
+    const size_t ce = c.num_labels > 0 ? b.blob_f32(px + "class_embed.weight") : 0;
     const size_t emb_off = b.alloc_misc((size_t)c.max_batch * E);
     const size_t gemb_off = b.alloc_misc((size_t)c.max_batch * E);
     const int NL = c.num_labels;
@@ -834,15 +910,15 @@ int build_model(vqvs_model* m, const float* const* hp) {
       condp = b.new_tensor(base, 8, false, false);
       PackedConv pk;
       Builder::SegSpec g{ct, 0, CC, 3, 1, RESIZE_NONE, false, 0, 0, 0, 0};
-      g.w_off = pk.append(b.P("cond_proj.weight"), base, CC, 3, 0, CC);
-      const float* bb = b.P("cond_proj.bias");
+      g.w_off = pk.append(b.P(px + "cond_proj.weight"), base, CC, 3, 0, CC);
+      const float* bb = b.P(px + "cond_proj.bias");
       b.add_conv({g}, pk, std::vector<float>(bb, bb + base), base, condp, nullptr, 0);
       b.release(ct);
     }
     // ---- in_conv
     TensorH h = b.new_tensor(base, 0, false, true);
     {
-      const size_t w = b.blob_f32("in_conv.weight"), bi = b.blob_f32("in_conv.bias");
+      const size_t w = b.blob_f32(px + "in_conv.weight"), bi = b.blob_f32(px + "in_conv.bias");
       const TensorH cp = condp;
       m->meta.push_back({"in_conv", "1->" + std::to_string(base), base + (has_cond ? base / 256.0 : 0.0), 4.0, 0});
       m->add_op([=](const RunCtx& r) -> int {
@@ -866,8 +942,11 @@ int build_model(vqvs_model* m, const float* const* hp) {
     std::vector<TensorH> skips{h};
     b.retain(h);  // one reference held by `h`, one by the stack
     size_t bi = 0;
+    std::vector<Builder::BlockRec> recs(all.size());
+    auto recp = [&](size_t i) { return encpred ? &recs[i] : nullptr; };
     for (auto& s : d) {
-      TensorH o = b.resblock(s.prefix, s, {h}, true, film_row[bi++], R, film_off);
+      TensorH o = b.resblock(s.prefix, s, {h}, true, film_row[bi], R, film_off, recp(bi));
+      ++bi;
       b.release(h);
       h = o;
       skips.push_back(h);
@@ -875,7 +954,8 @@ int build_model(vqvs_model* m, const float* const* hp) {
       b.tap(s.prefix, h);
     }
     for (auto& s : mdl) {
-      TensorH o = b.resblock(s.prefix, s, {h}, true, film_row[bi++], R, film_off);
+      TensorH o = b.resblock(s.prefix, s, {h}, true, film_row[bi], R, film_off, recp(bi));
+      ++bi;
       b.release(h);
       h = o;
       b.tap(s.prefix, h);
@@ -885,25 +965,27 @@ int build_model(vqvs_model* m, const float* const* hp) {
       if (s.cat) {
         TensorH sk = skips.back();
         skips.pop_back();
-        o = b.resblock(s.prefix, s, {h, sk}, true, film_row[bi++], R, film_off);
+        o = b.resblock(s.prefix, s, {h, sk}, true, film_row[bi], R, film_off, recp(bi));
         b.release(sk);
       } else {
-        o = b.resblock(s.prefix, s, {h}, true, film_row[bi++], R, film_off);
+        o = b.resblock(s.prefix, s, {h}, true, film_row[bi], R, film_off, recp(bi));
       }
+      ++bi;
       b.release(h);
       h = o;
       b.tap(s.prefix, h);
     }
     // ---- output head (unet.py:113-116, 162)
     const size_t ss = b.alloc_ss(base);
-    b.add_gn({h}, "out.0.0", false, 0, 0, 0, ss);
+    const size_t mr_out = encpred ? b.alloc_ss(base) : 0;
+    b.add_gn({h}, px + "out.0.0", false, 0, 0, 0, ss, encpred, mr_out);
     if (c.out_channels == 1) {
-      const float* W = b.P("out.1.weight");  // [1][base][3] -> [3][base]
+      const float* W = b.P(px + "out.1.weight");  // [1][base][3] -> [3][base]
       std::vector<float> wt(3 * base);
       for (int k = 0; k < 3; ++k)
         for (int ci = 0; ci < base; ++ci) wt[k * base + ci] = W[ci * 3 + k];
       const size_t w = b.blob.add(wt.data(), wt.size() * 4);
-      const float bias = b.P("out.1.bias")[0];
+      const float bias = b.P(px + "out.1.bias")[0];
       m->meta.push_back({"out_conv", std::to_string(base) + "->1", (double)base, 4.0, 0});
       m->add_op([=](const RunCtx& r) -> int {
         OutConvArgs a{};
@@ -920,12 +1002,78 @@ int build_model(vqvs_model* m, const float* const* hp) {
       TensorH o = b.new_tensor(c.out_channels, 0, true, false);
       PackedConv pk;
       Builder::SegSpec g{h, 0, base, 3, 1, RESIZE_NONE, true, ss, base, 0, 0};
-      g.w_off = pk.append(b.P("out.1.weight"), c.out_channels, base, 3, 0, base);
-      const float* bb = b.P("out.1.bias");
+      g.w_off = pk.append(b.P(px + "out.1.weight"), c.out_channels, base, 3, 0, base);
+      const float* bb = b.P(px + "out.1.bias");
       b.add_conv({g}, pk, std::vector<float>(bb, bb + c.out_channels), c.out_channels, o, nullptr, 0);
       const int OC = c.out_channels;
-      m->meta.push_back({"ntc_to_nct", "", 0, 0, 0});
-      m->add_op([=](const RunCtx& r) -> int { return launch_ntc_to_nct(bp->act(o.off), r.out, r.B, OC, r.Lbase, 0, r.st); });
+      if (!encpred) {
+        m->meta.push_back({"ntc_to_nct", "", 0, 0, 0});
+        m->add_op([=](const RunCtx& r) -> int { return launch_ntc_to_nct(bp->act(o.off), r.out, r.B, OC, r.Lbase, 0, r.st); });
+      } else {
+        // ---- EncoderPredictor head + backward schedule (vq_vae.py:125-130: grads of the summed cross-entropy)
+        const int D = c.reserved[2], rate = c.reserved[1];
+        const size_t hw = b.blob_f32("out.weight"), hb = b.blob_f32("out.bias");
+        b.persist = false;
+        TensorH dO = b.new_tensor(OC, 0, false, false);
+        const int es = b.es();
+        m->meta.push_back({"enc_head", "D=" + std::to_string(D), 0, 0, 0});
+        m->add_op([=](const RunCtx& r) -> int {
+          if (r.backward) VQVS_HIP(hipMemsetAsync(bp->act(dO.off), 0, (size_t)r.B * r.Lbase * OC * es, r.st));
+          EncHeadArgs a{};
+          a.o = reinterpret_cast<const float*>(bp->act(o.off));
+          a.w = reinterpret_cast<const float*>(bp->wp(hw));
+          a.bias = reinterpret_cast<const float*>(bp->wp(hb));
+          a.logits = r.out;
+          a.targets = r.backward ? r.labels : nullptr;
+          a.gscale = r.gscale;
+          a.dO = bp->act(dO.off);
+          a.Cb = OC;
+          a.D = D;
+          a.T = r.Lbase;
+          a.T1 = r.Lbase / rate;
+          a.rate = rate;
+          return launch_enc_head(a, r.B, prec, r.st);
+        });
+        m->cur_phase = 1;
+        // out.1 (3-tap conv base -> bottleneck over gelu(GN(h))) backwards: conv^T, gelu', GroupNorm backward
+        TensorH t = b.new_tensor(base, 0, false, false);
+        b.add_conv_t(dO, b.P(px + "out.1.weight"), OC, base, 3, 1, t);
+        b.release(dO);
+        const size_t po = b.alloc_stats(base, 0);
+        b.add_bw_act(t, BW_SAME, h, ss, t, po);
+        const size_t cfo = b.add_gn_bw(base, 0, po, ss, mr_out);
+        b.add_bw_affine(t, h, cfo, nullptr, BW_SAME, nullptr, t);
+        // blocks in reverse; gradients of skip-stack tensors wait in `pending` until the down path reaches their producer
+        std::map<int, TensorH> pending;
+        TensorH g2 = t;
+        auto add_pending = [&](const TensorH& produced) {  // produced = forward tensor whose gradient g2 currently is
+          auto it = pending.find(produced.id);
+          if (it == pending.end()) return;
+          b.add_bw_add(g2, it->second, g2);
+          b.release(it->second);
+          pending.erase(it);
+        };
+        for (size_t i = all.size(); i-- > 0;) {
+          add_pending(recs[i].out);
+          TensorH dsk{};
+          g2 = b.resblock_backward(recs[i], g2, &dsk);
+          if (recs[i].x2.id >= 0) pending[recs[i].x2.id] = dsk;
+        }
+        add_pending(recs[0].x);  // in_conv output: also the first skip-stack entry
+        const TensorH gi = g2;
+        const size_t inw = b.blob_f32(px + "in_conv.weight");
+        m->meta.push_back({"in_conv_bw", std::to_string(base) + "->1", (double)base, 4.0, 0});
+        m->add_op([=](const RunCtx& r) -> int {
+          InConvBwArgs a{};
+          a.dh = bp->act(gi.off);
+          a.w = reinterpret_cast<const float*>(bp->wp(inw));
+          a.out = r.grad_out;
+          a.C = base;
+          a.T = r.Lbase;
+          return launch_in_conv_bw(a, r.B, prec, r.st);
+        });
+        m->cur_phase = 0;
+      }
     }
   } else if (c.kind == VQVS_KIND_CLASSIFIER) {
     // Classifier.forward (classifier.py:31-36, 111-121) + the input gradient used by cond_fn (sample_diffusion.py:34-42)

@@ -54,15 +54,9 @@ class VQVAE(DiffusionModel):
         else:
             raise ValueError(f"unsupported codes shape: {codes.shape}")
         cond_fn = None
-        if enc_pred is not None:
+        if enc_pred is not None:  # vq_vae.py:123-130: guidance towards the codes, gradient from the native backward schedule
             targets = self.vq.encode(cond_seq)
-
-            def cond_fn(x, ts):
-                with torch.enable_grad():
-                    xg = x.detach().clone().requires_grad_(True)
-                    losses = enc_pred.losses(xg, ts, targets) * targets.shape[-1]
-                    grads = torch.autograd.grad(losses.sum(), xg)[0]
-                return grads * enc_pred_scale * -1
+            cond_fn = enc_pred.guidance_fn(targets, enc_pred_scale)
 
         T = codes.shape[-1] * self.encoder.downsample_rate
         seed = kwargs.pop("seed", None)
