@@ -44,5 +44,7 @@ def run(cin, cout, Lx, B, prec="bf16", dil=2, emb=256):
         print(f"   {name:18s} {v / waves:9.0f}  {100 * v / tot:5.1f}%")
 
 
-for shape in ((64, 64, 64000, 64), (128, 128, 16000, 64)):
+import ast
+shapes = ast.literal_eval(sys.argv[1]) if len(sys.argv) > 1 else ((64, 64, 64000, 64), (128, 128, 16000, 64), (256, 256, 2000, 64), (512, 512, 250, 64))
+for shape in shapes:
     run(*shape)
