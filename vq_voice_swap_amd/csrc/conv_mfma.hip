@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
   }
 #ifdef VQVS_TIMING
   TMARK(10)  // statistics reduce
-  if (lane == 0 && wave == 1 && (blockIdx.x & 15) == 3) {  // a 1/64 sample: the atomics must not become the workload
+  if (lane == 0 && wave == 1 && ((blockIdx.x + blockIdx.z) & 15) == 3) {  // a 1/64 sample: the atomics must not become the workload
     for (int i = 0; i < 18; ++i) atomicAdd(&g_conv_timing[i], tacc[i]);
     atomicAdd(&g_conv_timing[23], 1ull);
   }
