@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void in_conv_bw_kernel(const InConvBwArgs a) {
 // ------------------------------------------------------------------------------------
 // classifier head, forward and (optionally) backward.  256 threads per clip.
 // ------------------------------------------------------------------------------------
-constexpr int HEAD_NT = 256;
+constexpr int HEAD_NT = 1024;  // 16 waves: the head is one workgroup per clip and latency-bound, so breadth is what it needs
 constexpr int HEAD_MAXH = 16;
 
 template <typename T>
@@ -394,37 +394,47 @@ __global__ __launch_bounds__(HEAD_NT) void cls_head_kernel(const HeadArgs a) {
   }
   __syncthreads();
   // a[j] = bv[j] + Wv[j] . pooled[head(j)]     (the weights sum to one, so bv enters once)
-  for (int j = wv; j < C; j += NW) {
-    const float* w = a.wv + (size_t)j * C;
+  // forward mat-vecs: thread = output, walking a TRANSPOSED copy of the weights ([in][out]) so that a wave's loads
+  // coalesce; four independent partial sums keep several loads in flight
+  for (int j = tid; j < C; j += HEAD_NT) {
     const float* pl = pooled + (j / ch) * C;
-    float acc = 0.f;
-    for (int c = lane; c < C; c += 64) acc = fmaf(w[c], pl[c], acc);
-    acc = wave_sum_f(acc);
-    if (lane == 0) av[j] = acc + a.bv[j];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 2
+    for (int c = 0; c < C; c += 4) {
+      a0 = fmaf(a.wvT[(size_t)(c + 0) * C + j], pl[c + 0], a0);
+      a1 = fmaf(a.wvT[(size_t)(c + 1) * C + j], pl[c + 1], a1);
+      a2 = fmaf(a.wvT[(size_t)(c + 2) * C + j], pl[c + 2], a2);
+      a3 = fmaf(a.wvT[(size_t)(c + 3) * C + j], pl[c + 3], a3);
+    }
+    av[j] = ((a0 + a1) + (a2 + a3)) + a.bv[j];
   }
   __syncthreads();
-  for (int f = wv; f < F; f += NW) {
-    const float* w = a.wc + (size_t)f * C;
-    float acc = 0.f;
-    for (int c = lane; c < C; c += 64) acc = fmaf(w[c], av[c], acc);
-    acc = wave_sum_f(acc);
-    if (lane == 0) {
-      const float v = acc + a.bc[f];
-      feat[f] = v;
-      gl[f] = gelu_f(v);
+  for (int f = tid; f < F; f += HEAD_NT) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 2
+    for (int c = 0; c < C; c += 4) {
+      a0 = fmaf(a.wcT[(size_t)(c + 0) * F + f], av[c + 0], a0);
+      a1 = fmaf(a.wcT[(size_t)(c + 1) * F + f], av[c + 1], a1);
+      a2 = fmaf(a.wcT[(size_t)(c + 2) * F + f], av[c + 2], a2);
+      a3 = fmaf(a.wcT[(size_t)(c + 3) * F + f], av[c + 3], a3);
     }
+    const float v = ((a0 + a1) + (a2 + a3)) + a.bc[f];
+    feat[f] = v;
+    gl[f] = gelu_f(v);
   }
   __syncthreads();
-  for (int n = wv; n < NL; n += NW) {
-    const float* w = a.wl + (size_t)n * F;
-    float acc = 0.f;
-    for (int f = lane; f < F; f += 64) acc = fmaf(w[f], gl[f], acc);
-    acc = wave_sum_f(acc);
-    if (lane == 0) {
-      const float v = acc + a.bl[n];
-      lg[n] = v;
-      a.logits[(size_t)b * NL + n] = v;
+  for (int n = tid; n < NL; n += HEAD_NT) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 2
+    for (int f = 0; f < F; f += 4) {
+      a0 = fmaf(a.wlT[(size_t)(f + 0) * NL + n], gl[f + 0], a0);
+      a1 = fmaf(a.wlT[(size_t)(f + 1) * NL + n], gl[f + 1], a1);
+      a2 = fmaf(a.wlT[(size_t)(f + 2) * NL + n], gl[f + 2], a2);
+      a3 = fmaf(a.wlT[(size_t)(f + 3) * NL + n], gl[f + 3], a3);
     }
+    const float v = ((a0 + a1) + (a2 + a3)) + a.bl[n];
+    lg[n] = v;
+    a.logits[(size_t)b * NL + n] = v;
   }
   if (!a.labels) return;
   __syncthreads();
@@ -455,22 +465,42 @@ __global__ __launch_bounds__(HEAD_NT) void cls_head_kernel(const HeadArgs a) {
   }
   __syncthreads();
   for (int f = tid; f < F; f += HEAD_NT) {  // d feat
-    float acc = 0.f;
-    for (int n = 0; n < NL; ++n) acc = fmaf(a.wl[(size_t)n * F + f], lg[n], acc);
-    feat[f] = acc * gelu_grad_f(feat[f]);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int n = 0;
+#pragma unroll 2
+    for (; n + 4 <= NL; n += 4) {
+      a0 = fmaf(a.wl[(size_t)(n + 0) * F + f], lg[n + 0], a0);
+      a1 = fmaf(a.wl[(size_t)(n + 1) * F + f], lg[n + 1], a1);
+      a2 = fmaf(a.wl[(size_t)(n + 2) * F + f], lg[n + 2], a2);
+      a3 = fmaf(a.wl[(size_t)(n + 3) * F + f], lg[n + 3], a3);
+    }
+    for (; n < NL; ++n) a0 = fmaf(a.wl[(size_t)n * F + f], lg[n], a0);
+    feat[f] = ((a0 + a1) + (a2 + a3)) * gelu_grad_f(feat[f]);
   }
   __syncthreads();
   for (int j = tid; j < C; j += HEAD_NT) {  // d a
-    float acc = 0.f;
-    for (int f = 0; f < F; ++f) acc = fmaf(a.wc[(size_t)f * C + j], feat[f], acc);
-    av[j] = acc;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 2
+    for (int f = 0; f < F; f += 4) {
+      a0 = fmaf(a.wc[(size_t)(f + 0) * C + j], feat[f + 0], a0);
+      a1 = fmaf(a.wc[(size_t)(f + 1) * C + j], feat[f + 1], a1);
+      a2 = fmaf(a.wc[(size_t)(f + 2) * C + j], feat[f + 2], a2);
+      a3 = fmaf(a.wc[(size_t)(f + 3) * C + j], feat[f + 3], a3);
+    }
+    av[j] = (a0 + a1) + (a2 + a3);
   }
   __syncthreads();
   for (int c = tid; c < C; c += HEAD_NT) {  // d pooled[h][c] = sum_{j in head h} Wv[j][c] * da[j]
     for (int h = 0; h < H; ++h) {
-      float acc = 0.f;
-      for (int j = h * ch; j < (h + 1) * ch; ++j) acc = fmaf(a.wv[(size_t)j * C + c], av[j], acc);
-      pooled[h * C + c] = acc;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 2
+      for (int j = h * ch; j < (h + 1) * ch; j += 4) {
+        a0 = fmaf(a.wv[(size_t)(j + 0) * C + c], av[j + 0], a0);
+        a1 = fmaf(a.wv[(size_t)(j + 1) * C + c], av[j + 1], a1);
+        a2 = fmaf(a.wv[(size_t)(j + 2) * C + c], av[j + 2], a2);
+        a3 = fmaf(a.wv[(size_t)(j + 3) * C + c], av[j + 3], a3);
+      }
+      pooled[h * C + c] = (a0 + a1) + (a2 + a3);
     }
   }
   __syncthreads();

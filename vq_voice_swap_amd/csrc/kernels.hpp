@@ -204,11 +204,14 @@ struct HeadArgs {
   double inv_count;
   const float* r;      // [heads][C]  ch^-1/2 * Wk_h^T bq_h   (query token is constant: its input is zero)
   const float* c0;     // [heads]     ch^-1/2 * bq_h . bk_h
-  const float* wv;     // [C][C] value rows of qkv_proj
+  const float* wv;     // [C][C] value rows of qkv_proj   (backward walks the row-major matrices by column,
+  const float* wvT;    // [C][C] transposed                 the forward the transposed copies: both coalesce)
   const float* bv;     // [C]
   const float* wc;     // [F][C] c_proj
+  const float* wcT;    // [C][F]
   const float* bc;     // [F]
   const float* wl;     // [NL][F] out.1
+  const float* wlT;    // [F][NL]
   const float* bl;     // [NL]
   float* logits;       // [B][NL] out
   const int64_t* labels;  // [B] or nullptr = forward only

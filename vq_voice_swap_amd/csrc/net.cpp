@@ -1167,6 +1167,9 @@ int build_model(vqvs_model* m, const float* const* hp) {
     }
     const size_t r_off = b.blob.add(rvec.data(), rvec.size() * 4), c0_off = b.blob.add(c0.data(), c0.size() * 4);
     const size_t wv_off = b.blob.add(Wqkv + (size_t)2 * cur * cur, (size_t)cur * cur * 4);
+    const size_t wvT_off = b.blob_f32_transposed(Wqkv + (size_t)2 * cur * cur, cur, cur);
+    const size_t wcT_off = b.blob_f32_transposed(b.P("stem.out.1.c_proj.weight"), F, cur);
+    const size_t wlT_off = b.blob_f32_transposed(b.P("out.1.weight"), NL, F);
     const size_t bv_off = b.blob.add(bqkv + 2 * cur, (size_t)cur * 4);
     const size_t wc_off = b.blob_f32("stem.out.1.c_proj.weight"), bc_off = b.blob_f32("stem.out.1.c_proj.bias");
     const size_t wl_off = b.blob_f32("out.1.weight"), bl_off = b.blob_f32("out.1.bias");
@@ -1190,6 +1193,9 @@ int build_model(vqvs_model* m, const float* const* hp) {
       a.r = reinterpret_cast<const float*>(bp->wp(r_off));
       a.c0 = reinterpret_cast<const float*>(bp->wp(c0_off));
       a.wv = reinterpret_cast<const float*>(bp->wp(wv_off));
+      a.wvT = reinterpret_cast<const float*>(bp->wp(wvT_off));
+      a.wcT = reinterpret_cast<const float*>(bp->wp(wcT_off));
+      a.wlT = reinterpret_cast<const float*>(bp->wp(wlT_off));
       a.bv = reinterpret_cast<const float*>(bp->wp(bv_off));
       a.wc = reinterpret_cast<const float*>(bp->wp(wc_off));
       a.bc = reinterpret_cast<const float*>(bp->wp(bc_off));
