@@ -34,12 +34,18 @@ def run(cin, cout, Lx, B, prec="bf16", dil=2, emb=256):
     e = torch.randn(B, emb, device=dev)
     m(x, e)
     read()
+    m(x, e)
+    t1 = read()
+    print(f"    one ResBlock (two conv launches incl. the gap between them): workgroup starts spread {t1[18] / 100:.1f} us, "
+          f"ends spread {t1[19] / 100:.1f} us, first start -> last end {t1[20] / 100:.1f} us, first start -> first end {t1[21] / 100:.1f} us")
     for _ in range(3):
         m(x, e)
     t = read()
     waves = t[23]
     tot = sum(t[:18])
-    print(f"--- ResBlock {cin}->{cout} L={Lx} B={B} {prec} d={dil}: {waves} waves, {tot / waves:.0f} cycles/wave (both convs)")
+    # NOTE: an s_memtime tick is NOT a shader cycle here: 12.2k ticks = 9.7 us = 19.4k SQ_WAVE_CYCLES for a 64->64 wave-tile,
+    # i.e. ~1.26 ticks per ns (~0.63 shader cycles per tick at 2.0 GHz).  Percentages are what this table is for.
+    print(f"--- ResBlock {cin}->{cout} L={Lx} B={B} {prec} d={dil}: {waves} waves, {tot / waves:.0f} ticks/wave (both convs)")
     for name, v in zip(PH, t[:18]):
         print(f"   {name:18s} {v / waves:9.0f}  {100 * v / tot:5.1f}%")
 

@@ -25,6 +25,7 @@
 // every wave accumulates s_memtime deltas per phase and adds them to g_conv_timing at exit.
 #ifdef VQVS_TIMING
 __device__ unsigned long long g_conv_timing[24];
+__device__ unsigned long long g_conv_span[4] = {~0ull, 0ull, ~0ull, 0ull};  // min/max workgroup start, min/max end (wall clock, 100 MHz)
 #define TMARK(i)                                                    \
   {                                                                 \
     const unsigned long long _t = __builtin_amdgcn_s_memtime();     \
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
 #ifdef VQVS_TIMING
   unsigned long long tacc[18] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tlast = __builtin_amdgcn_s_memtime();
+  const unsigned long long wall0 = wall_clock64();
 #endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -476,6 +478,13 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
   }
 #ifdef VQVS_TIMING
   TMARK(10)  // statistics reduce
+  if (tid == 0) {
+    const unsigned long long wall1 = wall_clock64();
+    atomicMin(&g_conv_span[0], wall0);
+    atomicMax(&g_conv_span[1], wall0);
+    atomicMin(&g_conv_span[2], wall1);
+    atomicMax(&g_conv_span[3], wall1);
+  }
   if (lane == 0 && wave == 1 && ((blockIdx.x + blockIdx.z) & 15) == 3) {  // a 1/64 sample: the atomics must not become the workload
     for (int i = 0; i < 18; ++i) atomicAdd(&g_conv_timing[i], tacc[i]);
     atomicAdd(&g_conv_timing[23], 1ull);
@@ -544,6 +553,18 @@ int conv_lds_bytes(int precision, int wn) {
 int conv_timing_read(unsigned long long* out16, int reset) {
   VQVS_HIP(hipDeviceSynchronize());
   VQVS_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_conv_timing), 24 * sizeof(unsigned long long)));
+  {  // workgroup start / end spread of the launches since the last reset, in slots 18..21 (100 MHz ticks)
+    unsigned long long sp[4];
+    VQVS_HIP(hipMemcpyFromSymbol(sp, HIP_SYMBOL(g_conv_span), sizeof(sp)));
+    out16[18] = sp[1] - sp[0];  // latest start - earliest start
+    out16[19] = sp[3] - sp[2];  // latest end - earliest end
+    out16[20] = sp[3] - sp[0];  // whole span
+    out16[21] = sp[2] - sp[0];  // earliest end - earliest start
+    if (reset) {
+      const unsigned long long init[4] = {~0ull, 0ull, ~0ull, 0ull};
+      VQVS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_conv_span), init, sizeof(init)));
+    }
+  }
   if (reset) {
     unsigned long long z[24] = {};
     VQVS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_conv_timing), z, sizeof(z)));
