@@ -169,7 +169,7 @@ def main():
         # HBM traffic of the same launches from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE are
         # collected in separate --pmc runs; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950)
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_per_op_unet64_bf16.csv")
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_per_op_unet64_bf16.csv")  # tools/pmc_traffic.sh
         if a.model == "unet64" and a.precision == "bf16" and B == 64 and a.T == 64000 and os.path.exists(pmc):
             import csv
 
@@ -181,7 +181,7 @@ def main():
         ach = conv["bytes"] / (conv["ms"] * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None if traffic is None else round(traffic),
-                "traffic_note": "HBM bytes per launch from profiles/r01_pmc_per_op_unet64_bf16.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                "traffic_note": "HBM bytes per launch from profiles/r01_pmc_traffic_per_op_unet64_bf16.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                 "passes, FETCH_SIZE x2 on gfx950); algorithmic bytes per launch = algorithmic_bytes_per_forward / launches",
                 "kernel": "conv_mfma_kernel", "launches_per_forward": conv["launches"],
                 "avg_launch_us": round(conv["ms"] * 1e3 / conv["launches"], 2),
