@@ -115,3 +115,29 @@ def test_guided_sampling_vs_oracle():
                                       noise=[n.to(dev) for n in noises]).cpu()
     assert rms(got - want) < 1e-3
     assert rms(want - plain) > 10 * rms(got - want), "guidance term too small for the comparison to mean anything"
+
+
+@pytest.mark.gpu
+def test_guided_sampling_with_time_remap_and_sigma_large():
+    """cond_fn together with a sample-time schedule (diffusion.py:116-118) and sigma_large.
+    (Not with the cos noise schedule: its first iteration has alpha_bar(1) = cos^2(pi/2) ~ 2e-15, the constrain step then
+    subtracts a float32 mean from values of magnitude 1e7 and the reference's own result depends on its summation order
+    -- DESIGN.md section 4.)"""
+    dev = torch.device("cuda:0")
+    model = DiffusionModel("unet", 32, schedule_name="exp")
+    det_init_(model.state_dict().items())
+    model.eval()
+    clf = make_classifier()
+    sd_m = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    sd_c = {k: v.detach().clone() for k, v in clf.state_dict().items()}
+    labels = torch.tensor([0, 6, 2])
+    x_T = seeded((3, 1, 4096), 91)
+    gen = torch.Generator().manual_seed(92)
+    noises = [torch.randn(x_T.shape, generator=gen) for _ in range(3)]
+    tmap = lambda t: t ** 2  # noqa: E731
+    want = ref_cpu.ddpm_sample("exp", x_T, lambda a, b: ref_cpu.unet_predictor(sd_m, 32, a, b), 3, noises, sigma_large=True,
+                               constrain=True, cond_fn=ref_cpu.classifier_cond_fn(sd_c, 32, labels, 50.0), t_map=tmap)
+    clf.to(dev)
+    got = model.diffusion.ddpm_sample(x_T.to(dev), model.predictor, 3, sigma_large=True, constrain=True, schedule=tmap,
+                                      cond_fn=clf.guidance_fn(labels.to(dev), 50.0), noise=[n.to(dev) for n in noises]).cpu()
+    assert rms(got - want) < 1e-3

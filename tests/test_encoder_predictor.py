@@ -81,3 +81,24 @@ def test_encpred_guided_decode_vs_oracle():
                        noise=[n.to(dev) for n in noises]).cpu()
     assert rms(got - want) < 1e-3
     assert rms(want - plain) > 10 * rms(got - want), "guidance term too small for the comparison to mean anything"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,rate", [(1, 2048, 256), (3, 4096, 512)])
+def test_encpred_small_shapes_vs_oracle(B, T, rate):
+    """single clip / odd batch / a coarser latent rate, per-clip timesteps; handle re-used across shapes."""
+    dev = torch.device("cuda:0")
+    ep = EncoderPredictor(base_channels=32, downsample_rate=rate, num_latents=40, bottleneck_dim=32)
+    det_init_(ep.state_dict().items())
+    ep.eval()
+    sd = {k: v.detach().clone() for k, v in ep.state_dict().items()}
+    x = seeded((B, 1, T), 101 + B)
+    ts = torch.linspace(0.2, 0.9, B)
+    targets = torch.randint(0, 40, (B, T // rate), generator=torch.Generator().manual_seed(5))
+    want = ref_cpu.encoder_predictor(sd, 32, x, ts, rate)
+    want_g = ref_cpu.encoder_predictor_cond_fn(sd, 32, rate, targets, 2.0)(x, ts)
+    ep.to(dev)
+    assert rel_rms(ep(x.to(dev), ts.to(dev)).cpu(), want) < 2e-4
+    assert rel_rms(ep.guidance_grad(x.to(dev), ts.to(dev), targets.to(dev), 2.0).cpu(), want_g) < 2e-3
+    with pytest.raises(ValueError):
+        ep.guidance_grad(x.to(dev), ts.to(dev), targets[:, :-1].to(dev))
