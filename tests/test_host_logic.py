@@ -115,3 +115,18 @@ def test_two_rank_gather_gloo(tmp_path):
                         "--master-port", "29531", str(script)], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "GATHER_OK" in r.stdout
+
+
+def test_plain_c_client_of_the_abi(tmp_path, lib_built):
+    """examples/abi_info.c: the header is self-contained C and the host-side entry points work without torch."""
+    import numpy as np
+
+    exe = str(tmp_path / "abi_info")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "abi_info.c"),
+                    "-ldl", "-o", exe], check=True)
+    out = subprocess.run([exe, _native.LIB_PATH, "32"], check=True, capture_output=True, text=True).stdout
+    cfg = _native.Cfg()
+    cfg.kind, cfg.base_channels, cfg.in_channels, cfg.out_channels, cfg.max_batch, cfg.max_T = 0, 32, 1, 1, 1, 256
+    table = _native.param_table(cfg)
+    assert f"{len(table)} parameters" in out and "time_embed.proj.weight" in out
+    assert f"total {sum(int(np.prod(s)) for _, s in table)} float32 values" in out
