@@ -19,7 +19,9 @@
  *   - return value 0 = success, negative = error (vqvs_last_error() describes
  *     it, thread-local).  Nothing here falls back to a CPU path.
  *   - a handle is not thread-safe (one scratch arena); different handles are
- *     independent.  One process per GPU.
+ *     independent.  The handle-less entry points (vqvs_ddpm_step with CONSTRAIN,
+ *     vqvs_vq_argmin) share one small per-process scratch buffer: issue them from
+ *     one thread and one stream at a time.  One process per GPU.
  */
 #ifndef VQVS_H
 #define VQVS_H
