@@ -138,12 +138,27 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
   const int lane = tid & 63;
   const int wave = (tid >> 6) & 3;   // position along time
   const int wvn = tid >> 8;          // position along output channels (0 .. WGN-1)
-  const int b = blockIdx.z;
-  const int co0 = blockIdx.y * CT;
+  // XCD-aware tile order.  Workgroup `lin` (x fastest) is dispatched to XCD lin % 8, each XCD with its own L2: give every
+  // XCD one CONTIGUOUS run of tiles, ordered output-channel tile fastest (co-tiles re-read the same input rows), then
+  // time (neighbours share their halo rows), then clip -- so those re-reads hit the XCD's L2 instead of crossing dies.
+  int tile_x, tile_y, tile_b;
+  {
+    const int nx = (int)gridDim.x, ny = (int)gridDim.y;
+    const int total = nx * ny * (int)gridDim.z;
+    const int lin = (int)blockIdx.x + nx * ((int)blockIdx.y + ny * (int)blockIdx.z);
+    const int k = lin & 7, j = lin >> 3;           // XCD, position within the XCD's run
+    const int q = total >> 3, r = total & 7;        // XCD k owns q + (k < r) tiles, starting at k*q + min(k, r)
+    const int id = k * q + (k < r ? k : r) + j;
+    tile_y = id % ny;
+    tile_x = (id / ny) % nx;
+    tile_b = id / (ny * nx);
+  }
+  const int b = tile_b;
+  const int co0 = tile_y * CT;
   // A tile produces tile_rows = 256 - 2*dmax output rows, so that rows + halo = 256 staged rows = a whole number
   // of (row, octet) items per thread: no wave carries an extra, mostly empty, halo item to every barrier.
   const int TTO = a.tile_rows;
-  const int t0 = blockIdx.x * TTO;
+  const int t0 = tile_x * TTO;
   const int oct = tid & 3;
   const int l31 = lane & 31;
   const int khalf = (lane >> 5) * 16;
@@ -471,7 +486,7 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
         t1 += red[(g * CT + tid) * 2 + 0];
         t2 += red[(g * CT + tid) * 2 + 1];
       }
-      float* o = a.stats + (((size_t)b * a.ntiles + blockIdx.x) * a.Cout + co0 + tid) * 2;
+      float* o = a.stats + (((size_t)b * a.ntiles + tile_x) * a.Cout + co0 + tid) * 2;
       o[0] = t1;
       o[1] = t2;
     }
@@ -485,7 +500,7 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
     atomicMin(&g_conv_span[2], wall1);
     atomicMax(&g_conv_span[3], wall1);
   }
-  if (lane == 0 && wave == 1 && ((blockIdx.x + blockIdx.z) & 15) == 3) {  // a 1/64 sample: the atomics must not become the workload
+  if (lane == 0 && wave == 1 && ((tile_x + tile_b) & 15) == 3) {  // a 1/64 sample: the atomics must not become the workload
     for (int i = 0; i < 18; ++i) atomicAdd(&g_conv_timing[i], tacc[i]);
     atomicAdd(&g_conv_timing[23], 1ull);
   }
