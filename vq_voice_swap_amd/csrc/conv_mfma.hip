@@ -19,6 +19,8 @@
 //                distinct 16-byte slots (5*r mod 16 is a bijection) -> conflict free.
 //   VQVS_PREC_F32: operands are split x = hi + lo in bf16 and the product is evaluated as
 //                hi*hi + lo*hi + hi*lo with fp32 accumulation (drops only lo*lo ~ 2^-18).
+#include <cstdlib>
+
 #include "kernels.hpp"
 
 // Optional in-kernel phase timing (tools/conv_phases.py; build with -DVQVS_TIMING into a separate library):
@@ -112,11 +114,16 @@ struct IterGeom {
   int base_off, step;         // byte offset of the thread's first (row, octet) item in chunk 0; bytes between its items
   const float2* ssp;          // (scale, shift) of the thread's octet in chunk 0
   const void* avg_src;        // avg-pool path: the thread's octet of row 0, chunk 0
-  int Csrc;
+  int Csrc, c0;
   int wbase, wstep;           // byte offset of chunk 0 in the packed weights, bytes per chunk
 };
 
-template <typename T, bool X3, int WN, int HALO, bool SKIPV, int WGN, int WM>
+// DMA (all segments raw bf16, i.e. inputs already transformed by xform_kernel or untransformed skip-conv inputs): the
+// chunk goes from memory straight into LDS with `buffer_load_dwordx4 ... lds` -- no staging registers, no VALU, no
+// ds_write.  A wave-wide DMA writes 64 x 16 B contiguously, so the LDS rows are unpadded (64 B); bank conflicts of the
+// fragment reads are avoided by an XOR swizzle of the 16-byte column with bits 2..3 of the row, applied on the global
+// address side when loading and on the LDS address side when reading.
+template <typename T, bool X3, int WN, int HALO, bool SKIPV, int WGN, int WM, bool DMA>
 __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs a) {
   constexpr int TT = 4 * WM * 32;  // staged rows: 4 waves along time x WM MFMA tiles of 32 rows
   constexpr int NTH = 256 * WGN;  // 4 waves along time x WGN waves along output channels
@@ -161,7 +168,7 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
   const int t0 = tile_x * TTO;
   const int oct = tid & 3;
   const int l31 = lane & 31;
-  const int khalf = (lane >> 5) * 16;
+
 
   // ---- per-thread invariants of the staging loops (hoisted out of the K loop) ----
   int act_lds[NPF];   // LDS byte offset of (row r_i, octet)
@@ -227,6 +234,7 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
     g.ssp = g.xform ? sg.ss + (size_t)b * sg.ss_stride + sg.ss_c0 + oct * 8 : nullptr;
     g.avg_src = clip + sg.c0 + oct * 8;
     g.Csrc = sg.Csrc;
+    g.c0 = sg.c0;
     g.wbase = (int)(sg.w_off * 2);
     g.wstep = g.ntaps * a.Cout * 32 * 2;
     return g;
@@ -259,6 +267,38 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
       if constexpr (X3) rwl[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_wl, w_goff[i] + wbase, 0, 0);
     }
     TMARK(13)
+  };
+
+  // ---- DMA staging (see the template comment): 1 KiB pieces = 16 LDS rows of 64 B, dealt round-robin to the waves ----
+  constexpr int DROW = 64;
+  constexpr int D_ACT_BYTES = (TT + HALO) * DROW;
+  constexpr int D_BUF_BYTES = D_ACT_BYTES + 3 * CT * DROW;
+  auto dma_stage = [&](const IterGeom& g, int buf) {
+    if constexpr (DMA) {
+      typedef __attribute__((address_space(3))) void* lds_ptr;
+      const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+      constexpr int NWAVES = NTH / 64;
+      const int q = lane & 3, rl = lane >> 2;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.clip), 0, g.clip_bytes, 0x00020000);
+      char* const abuf = smem + buf * D_BUF_BYTES;
+      const int npa = (g.nrows + 15) >> 4;
+      for (int p = w8; p < npa; p += NWAVES) {
+        const int r = p * 16 + rl;
+        const int o = q ^ ((r >> 2) & 3);
+        const int voff = ((g.base_time + r) * g.Csrc + g.c0 + g.ch * 32 + o * 8) * 2;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(abuf + p * 1024), 16, voff, 0, 0, 0);
+      }
+      char* const wbuf = abuf + D_ACT_BYTES;
+      const int npw = (g.ntaps * CT) >> 4;
+      const int wbase = g.wbase + g.ch * g.wstep;
+      for (int p = w8; p < npw; p += NWAVES) {
+        const int r = p * 16 + rl;
+        const int tap = r / CT, col = r - tap * CT;
+        const int o = q ^ ((r >> 2) & 3);
+        const int voff = wbase + ((tap * a.Cout + co0 + col) * 32 + o * 8) * 2;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wh, (lds_ptr)(wbuf + p * 1024), 16, voff, 0, 0, 0);
+      }
+    }
   };
 
   auto store_stage = [&](const IterGeom& g, int buf) {
@@ -322,34 +362,37 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
   };
 
   auto mfma_stage = [&](const IterGeom& g, int buf) {
-    const char* const act_hi = smem + buf * BUF_BYTES;
+    const char* const act_hi = DMA ? smem + buf * D_BUF_BYTES : smem + buf * BUF_BYTES;
     const char* const act_lo = act_hi + ACT_BYTES;
-    const char* const w_hi = act_hi + PLANES * ACT_BYTES;
+    const char* const w_hi = DMA ? act_hi + D_ACT_BYTES : act_hi + PLANES * ACT_BYTES;
     const char* const w_lo = w_hi + W_BYTES;
-    int wb[WN];  // B-fragment (weights) byte offsets: constant per lane
-#pragma unroll
-    for (int nt = 0; nt < WN; ++nt) wb[nt] = ((wvn * WN + nt) * 32 + l31) * ROWB + khalf;
+    constexpr int RB = DMA ? DROW : ROWB;  // LDS row pitch
+    // byte address of k-octet `o` (0..3) of LDS row `r`: padded rows, or unpadded rows with the column swizzle
+    auto frag_addr = [&](int r, int o) { return DMA ? r * DROW + ((o ^ ((r >> 2) & 3)) << 4) : r * ROWB + (o << 4); };
+    const int ohalf = lane >> 5;
     for (int k = 0; k < g.ntaps; ++k) {
       const int toff = (g.ntaps == 3) ? (k - 1) * g.d : 0;
-      int ab[WM];  // A-fragment (activation) byte offsets for this tap
+      int ar[WM];  // LDS row of the A fragment (activation) for this tap
 #pragma unroll
       for (int mt = 0; mt < WM; ++mt) {
         const int tl = wave * (WM * 32) + mt * 32 + l31;
-        ab[mt] = (g.up ? (((tl + toff) >> 1) + 1) : (tl + toff + g.d)) * ROWB + khalf;
+        ar[mt] = g.up ? (((tl + toff) >> 1) + 1) : (tl + toff + g.d);
       }
-      const int wk = k * CT * ROWB;
+      const int wrow = k * CT;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8 ah[WM], al[WM], bh[WN], bl[WN];
 #pragma unroll
         for (int mt = 0; mt < WM; ++mt) {
-          ah[mt] = *reinterpret_cast<const bf16x8*>(act_hi + ab[mt] + ks * 32);
-          if constexpr (X3) al[mt] = *reinterpret_cast<const bf16x8*>(act_lo + ab[mt] + ks * 32);
+          const int ad = frag_addr(ar[mt], ks * 2 + ohalf);
+          ah[mt] = *reinterpret_cast<const bf16x8*>(act_hi + ad);
+          if constexpr (X3) al[mt] = *reinterpret_cast<const bf16x8*>(act_lo + ad);
         }
 #pragma unroll
         for (int nt = 0; nt < WN; ++nt) {
-          bh[nt] = *reinterpret_cast<const bf16x8*>(w_hi + wk + wb[nt] + ks * 32);
-          if constexpr (X3) bl[nt] = *reinterpret_cast<const bf16x8*>(w_lo + wk + wb[nt] + ks * 32);
+          const int ad = frag_addr(wrow + (wvn * WN + nt) * 32 + l31, ks * 2 + ohalf);
+          bh[nt] = *reinterpret_cast<const bf16x8*>(w_hi + ad);
+          if constexpr (X3) bl[nt] = *reinterpret_cast<const bf16x8*>(w_lo + ad);
         }
 #pragma unroll
         for (int mt = 0; mt < WM; ++mt)
@@ -363,6 +406,7 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
           }
       }
     }
+    (void)RB;
   };
 
   // epilogue geometry (needed early: the identity-skip rows are prefetched before the last MFMA phase)
@@ -385,6 +429,34 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
   {
     IterGeom cur = geom(0);
     TMARK(0)  // setup
+    if constexpr (DMA) {
+      // chunk it+1 streams into the other LDS buffer while the matrix cores work on chunk it.  The DMA is issued AFTER
+      // the barrier: every wave has then finished reading that buffer (chunk it-1).
+      dma_stage(cur, 0);
+      for (int it = 0; it < niter; ++it) {
+        const int buf = it & 1;
+        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's pieces of chunk `it` have landed
+        TMARK(2)
+        __syncthreads();
+        TMARK(4)
+        IterGeom nxt = cur;
+        if (it + 1 < niter) {
+          if (++nxt.ch == nxt.nch) nxt = geom(cur.s + 1);
+          dma_stage(nxt, buf ^ 1);
+        } else if (skip_pf) {
+#pragma unroll
+          for (int i = 0; i < (SKIP_PF ? NEP : 1); ++i) {
+            const int tm = t0 + r0 + RPP * i;
+            const int ts = a.skip_resize == RESIZE_UP2 ? (tm >> 1) : tm;
+            rsk[i].load(rs_skip, (ts * a.skip_C + cg) * (int)sizeof(T));
+          }
+        }
+        TMARK(1)
+        mfma_stage(cur, buf);
+        TMARK(5)
+        cur = nxt;
+      }
+    } else {
     issue_loads(cur);
     for (int it = 0; it < niter; ++it) {
       const int buf = it & 1;
@@ -423,6 +495,7 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
       TMARK(17)  // matrix-pipe drain
 #endif
       cur = nxt;
+    }
     }
   }
 
@@ -507,6 +580,15 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
 #endif
 }
 
+bool dma_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("VQVS_DMA");  // 0 = stage raw segments through registers (A/B measurements)
+    v = e ? atoi(e) : 1;
+  }
+  return v != 0;
+}
+
 template <bool X3, int WN, int HALO, int WGN = 1, int WM = 2>
 constexpr int lds_bytes() {
   constexpr int CT = WGN * WN * 32;
@@ -516,18 +598,18 @@ constexpr int lds_bytes() {
   return stage > ost ? stage : ost;
 }
 
-template <typename T, bool X3, int WN, int HALO, bool SKIPV, int WGN = 1, int WM = 2>
+template <typename T, bool X3, int WN, int HALO, bool SKIPV, int WGN = 1, int WM = 2, bool DMA = false>
 int launch_t(const ConvArgs& a, int B, hipStream_t st) {
   constexpr int LDS = lds_bytes<X3, WN, HALO, WGN, WM>();
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool attr_done = false;
   if (!attr_done) {
-    VQVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<T, X3, WN, HALO, SKIPV, WGN, WM>),
+    VQVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<T, X3, WN, HALO, SKIPV, WGN, WM, DMA>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_done = true;
   }
   dim3 grid((a.Lout + a.tile_rows - 1) / a.tile_rows, a.Cout / (WGN * WN * 32), B);
-  hipLaunchKernelGGL((conv_mfma_kernel<T, X3, WN, HALO, SKIPV, WGN, WM>), grid, dim3(256 * WGN), LDS, st, a);
+  hipLaunchKernelGGL((conv_mfma_kernel<T, X3, WN, HALO, SKIPV, WGN, WM, DMA>), grid, dim3(256 * WGN), LDS, st, a);
   VQVS_HIP(hipGetLastError());
   return 0;
 }
@@ -537,6 +619,13 @@ int launch_p(const ConvArgs& a, int B, hipStream_t st, bool wide, bool big_halo,
   if constexpr (!X3) {
     // 128-channel output tiles (8 waves): the prologue and the activation reads are shared by twice as many channels
     if (a.Cout % 128 == 0) {
+      bool raw = true;  // every segment untransformed and unresized-or-upsampled: stage by LDS-DMA
+      for (int s = 0; s < a.nseg; ++s) raw = raw && a.seg[s].ss == nullptr && a.seg[s].resize != RESIZE_AVG2;
+      // (measured on the 512-channel launches: -3...-5 % for plain, -10...-14 % with 1x1 skip-conv segments,
+      //  +4...+7 % with an identity skip, which therefore keeps the register path)
+      if (raw && a.skip == nullptr && dma_enabled()) {
+        return big_halo ? launch_t<T, X3, 2, 64, false, 2, 2, true>(a, B, st) : launch_t<T, X3, 2, 4, false, 2, 2, true>(a, B, st);
+      }
       if (a.skip != nullptr) return big_halo ? launch_t<T, X3, 2, 64, true, 2>(a, B, st) : launch_t<T, X3, 2, 4, true, 2>(a, B, st);
       return big_halo ? launch_t<T, X3, 2, 64, false, 2>(a, B, st) : launch_t<T, X3, 2, 4, false, 2>(a, B, st);
     }
