@@ -100,3 +100,39 @@ def test_sample_scripts_end_to_end(tmp_path):
     b = r.read(64000)
     r.close()
     assert b.shape == (64000,) and np.isfinite(b).all()
+
+
+@pytest.mark.gpu
+def test_cpp_host_samples_like_python(tmp_path):
+    """examples/sample_unet.cpp drives the sampler through include/vqvs.h alone (weights from tools/export_weights.py);
+    same seed -> the same clips as Diffusion.ddpm_sample (schedule values come from expf vs torch.exp: a few ulp)."""
+    import subprocess
+
+    import numpy as np
+    import torch
+
+    from vq_voice_swap_amd import DiffusionModel, _native, randn_clips
+    from vq_voice_swap_amd.det_init import det_init_
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import export_weights
+
+    model = DiffusionModel("unet", 32)
+    det_init_(model.state_dict().items())
+    model.eval()
+    wfile, ofile, exe = str(tmp_path / "w.bin"), str(tmp_path / "out.f32"), str(tmp_path / "sample_unet")
+    export_weights.export(model, wfile)
+    libdir = os.path.dirname(_native.LIB_PATH)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include",
+                    os.path.join(ROOT, "examples", "sample_unet.cpp"), "-L" + libdir, "-lvqvs_hip", "-L/opt/rocm/lib", "-lamdhip64",
+                    "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
+    B, T, steps, seed = 2, 4096, 4, 77
+    r = subprocess.run([exe, wfile, ofile, str(B), str(T), str(steps), str(seed), "0"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = torch.from_numpy(np.fromfile(ofile, dtype=np.float32).reshape(B, 1, T))
+    dev = torch.device("cuda:0")
+    model.to(dev)
+    x_T = randn_clips(B, T, dev, seed)
+    want = model.diffusion.ddpm_sample(x_T, model.predictor, steps, constrain=True, seed=seed).cpu()
+    assert (got - want).abs().max().item() < 1e-4
+    assert os.path.getsize(ofile + ".wav") == 44 + 2 * T
