@@ -102,3 +102,32 @@ def test_encpred_small_shapes_vs_oracle(B, T, rate):
     assert rel_rms(ep.guidance_grad(x.to(dev), ts.to(dev), targets.to(dev), 2.0).cpu(), want_g) < 2e-3
     with pytest.raises(ValueError):
         ep.guidance_grad(x.to(dev), ts.to(dev), targets[:, :-1].to(dev))
+
+
+@pytest.mark.gpu
+def test_base64_guidance_models_vs_oracle():
+    """Width 64 (512-channel levels: stand-alone prologue kernels, LDS-DMA staging, 8-head attention pool) for both
+    guidance models, forward and input gradient, fp32 mode."""
+    from vq_voice_swap_amd import Classifier
+
+    dev = torch.device("cuda:0")
+    ts = torch.tensor([0.2, 0.7])
+    clf = Classifier(num_labels=11, base_channels=64)
+    det_init_(clf.state_dict().items())
+    clf.eval()
+    sd = {k: v.detach().clone() for k, v in clf.state_dict().items()}
+    x = seeded((2, 1, 2048), 3)
+    labels = torch.tensor([3, 9])
+    want, want_g = ref_cpu.classifier(sd, 64, x, ts), ref_cpu.classifier_cond_fn(sd, 64, labels, 1.0)(x, ts)
+    clf.to(dev)
+    g, lg = clf.log_prob_grad(x.to(dev), ts.to(dev), labels.to(dev), 1.0, return_logits=True)
+    assert rel_rms(lg.cpu(), want) < 2e-4 and rel_rms(g.cpu(), want_g) < 2e-3
+    ep = EncoderPredictor(64, 256, 64)
+    det_init_(ep.state_dict().items())
+    ep.eval()
+    sd = {k: v.detach().clone() for k, v in ep.state_dict().items()}
+    tg = torch.randint(0, 64, (2, 8), generator=torch.Generator().manual_seed(1))
+    want, want_g = ref_cpu.encoder_predictor(sd, 64, x, ts, 256), ref_cpu.encoder_predictor_cond_fn(sd, 64, 256, tg, 1.0)(x, ts)
+    ep.to(dev)
+    assert rel_rms(ep(x.to(dev), ts.to(dev)).cpu(), want) < 2e-4
+    assert rel_rms(ep.guidance_grad(x.to(dev), ts.to(dev), tg.to(dev)).cpu(), want_g) < 2e-3
