@@ -771,6 +771,9 @@ static int check_cfg(const vqvs_cfg& c) {
   if (c.base_channels & (c.base_channels - 1)) VQVS_FAIL(VQVS_ERR_ARG, "base_channels must be a power of two (got %d)", c.base_channels);
   if (c.in_channels != 1) VQVS_FAIL(VQVS_ERR_ARG, "in_channels must be 1 (got %d)", c.in_channels);
   if (c.max_T % 256) VQVS_FAIL(VQVS_ERR_ARG, "max_T must be a multiple of 256 (got %d)", c.max_T);
+  // the kernels address rows of one clip with 32-bit byte offsets (buffer loads): the widest per-clip tensor must stay below 2 GiB
+  if ((long long)c.max_T * c.base_channels * 8 > 0x7fffffffLL)
+    VQVS_FAIL(VQVS_ERR_ARG, "max_T=%d is too long for base_channels=%d (a clip's top-level tensor would exceed 2 GiB)", c.max_T, c.base_channels);
   if (c.kind == VQVS_KIND_PREDICTOR) {
     if (c.out_channels != 1 && (c.out_channels % 32)) VQVS_FAIL(VQVS_ERR_ARG, "out_channels must be 1 or a multiple of 32");
     if (c.cond_channels % 32) VQVS_FAIL(VQVS_ERR_ARG, "cond_channels must be a multiple of 32");
