@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--model", default="unet64", choices=["unet32", "unet64"])
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step")
     ap.add_argument("--sample-steps", type=int, default=50)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--schedule", default="t**2", choices=["t", "t**2"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the extra fp32 (parity mode) measurement")

@@ -48,6 +48,9 @@ extern "C" {
 /* activation storage / arithmetic */
 #define VQVS_PREC_F32 0  /* fp32 activations; convs as 3-term bf16-split MFMA, fp32 accumulate (~2^-17 rel.) */
 #define VQVS_PREC_BF16 1 /* bf16 activations; bf16 MFMA, fp32 accumulate */
+#define VQVS_PREC_F16 2  /* fp16 (IEEE binary16) activations and weights; f16 MFMA, fp32 accumulate; GroupNorm statistics,
+                            FiLM, GELU and the residual add are evaluated in fp32.  Meets the 1e-3 waveform-RMS parity
+                            bar at 2-byte storage; activations must stay below 65504 in magnitude */
 
 typedef struct vqvs_model vqvs_model;
 
@@ -161,6 +164,9 @@ int vqvs_debug_tap_count(const vqvs_model* m);
 int vqvs_debug_tap_info(const vqvs_model* m, int i, char* name_out, int name_cap, int* channels, int* length_shift);
 /* copies tap i of the LAST forward to host as float32 NCT [B][C][L]; synchronises the device */
 int vqvs_debug_read_tap(vqvs_model* m, int i, int B, int T, float* h_out);
+/* copies the conditioning vector of the LAST forward -- time_embed_extra(time_embed(ts)) [+ class_embed(labels)], reference
+ * unet.py:133-135 with wavegrad.py:359-373 -- to host as float32 [B][4*base_channels]; returns its width; synchronises */
+int vqvs_debug_read_embedding(vqvs_model* m, int B, float* h_out);
 /* number of kernels one forward enqueues, and the algorithmic activation bytes it moves (SURVEY 8d Model A) */
 int vqvs_forward_kernel_count(const vqvs_model* m);
 int64_t vqvs_forward_model_bytes(const vqvs_model* m, int B, int T);

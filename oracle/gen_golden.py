@@ -312,6 +312,75 @@ def gen_encpred():
     save("f10_encpred32", x_seed=71, ts=ts, targets=targets, logits=logits.detach(), grad=grad)
 
 
+# ---------------------------------------------------------------- F2 timestep embedding (wavegrad.py:359-373, unet.py:133-135)
+def gen_time_embed():
+    out = {}
+    ts = torch.tensor([0.02, 0.5, 1.0])
+    for base in (32, 64):
+        model = det_model(DiffusionModel("unet", base, num_labels=6))
+        sd = state_of(model)
+        labels = torch.tensor([5, 0, 3])
+        with torch.no_grad():
+            t_emb = model.predictor.time_embed(ts)                              # sinusoid (args up to 100 rad) + Linear
+            emb = model.predictor.time_embed_extra(t_emb) + model.predictor.class_embed(labels)
+        check(f"time_embed C={base}", t_emb, ref_cpu.time_embedding(ts, sd, "predictor.time_embed"))
+        check(f"embedding C={base}", emb, ref_cpu.unet_embedding(sd, ts, labels))
+        out[f"c{base}.emb"] = emb
+        out[f"c{base}.labels"] = labels
+    save("f2_time_embed", ts=ts, **out)
+
+
+# ---------------------------------------------------------------- F5b ddpm_previous under the cosine schedule (schedule.py:34-41)
+def gen_ddpm_previous_cos():
+    model = DiffusionModel("unet", 32, schedule_name="cos")   # only .diffusion is used
+    diff = model.diffusion
+    cases = [(0.9, 0.1), (0.5, 0.02), (0.1, 0.02), (0.37, 0.01), (0.75, 0.25)]  # away from t = 1 (alpha_bar(1) ~ 4e-33)
+    out = {}
+    for i, (t, step) in enumerate(cases):
+        x, eps, noise = seeded((2, 1, 4096), 310 + i), seeded((2, 1, 4096), 410 + i), seeded((2, 1, 4096), 510 + i)
+        ts = torch.tensor([t, t])
+        for mode, kw in (("plain", {}), ("sigma_large", dict(sigma_large=True)), ("constrain", dict(constrain=True))):
+            y = diff.ddpm_previous(x, ts, step, eps, noise=noise, **kw)
+            check(f"cos ddpm_previous t={t} {mode}", y, ref_cpu.ddpm_previous("cos", x, ts, step, eps, noise, **kw))
+            out[f"c{i}.{mode}"] = y
+        out[f"c{i}.x"], out[f"c{i}.eps"], out[f"c{i}.noise"] = x, eps, noise
+        out[f"c{i}.t_step"] = np.array([t, step])
+    save("f5b_ddpm_previous_cos", **out)
+
+
+# ---------------------------------------------------------------- F11 decode_uncond_guidance (vq_vae.py:147-220)
+def gen_uncond_guidance():
+    import vq_voice_swap.diffusion.diffusion as dmod
+    import vq_voice_swap.vq_vae as vmod
+
+    model = det_model(VQVAE(base_channels=32, pred_name="unet", num_labels=5))  # label 0 = unconditional, 4 real labels
+    with torch.no_grad():
+        model.vq.dictionary.copy_(seeded(model.vq.dictionary.shape, 77, 0.35))
+    sd = state_of(model)
+    codes = torch.randint(0, 512, (2, 8), generator=torch.Generator().manual_seed(81))
+    labels = torch.tensor([0, 2])
+    steps, vq_scale, label_scale = 4, 1.5, 0.7
+    x_T = seeded((2, 1, 2048), 82)
+    gen = torch.Generator().manual_seed(83)
+    noises = [torch.randn(x_T.shape, generator=gen) for _ in range(steps)]
+    it = iter(noises)
+    orig_rl, orig_r = torch.randn_like, torch.randn
+    dmod.torch.randn_like = lambda t, *a, **k: next(it)
+    vmod.torch.randn = lambda *a, **k: x_T.clone()
+    try:
+        with torch.no_grad():
+            dec = model.decode_uncond_guidance(codes, labels, steps=steps, constrain=True, label_scale=label_scale, vq_scale=vq_scale)
+    finally:
+        dmod.torch.randn_like = orig_rl
+        vmod.torch.randn = orig_r
+    dec2 = ref_cpu.vqvae_decode_uncond_guidance(sd, 32, "exp", codes, labels, steps, x_T, noises, constrain=True,
+                                                label_scale=label_scale, vq_scale=vq_scale)
+    check("decode_uncond_guidance", dec, dec2, tol=1e-5)
+    print(f"  x0 rms={dec.pow(2).mean().sqrt().item():.4f}")
+    save("f11_uncond_guidance", x_T_seed=82, noise_seed=83, codes=codes, labels=labels, steps=steps,
+         scales=np.array([vq_scale, label_scale]), x0=dec)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     if not only or "resblocks" in only:
@@ -328,4 +397,10 @@ if __name__ == "__main__":
         gen_classifier()
     if not only or "encpred" in only:
         gen_encpred()
+    if not only or "time_embed" in only:
+        gen_time_embed()
+    if not only or "cos" in only:
+        gen_ddpm_previous_cos()
+    if not only or "uncond" in only:
+        gen_uncond_guidance()
     print("ok")

@@ -137,6 +137,16 @@ def time_embedding(ts: Tensor, sd: State, p: str) -> Tensor:
     return F.linear(torch.cat([torch.cos(args), torch.sin(args)], dim=-1), w, sd[p + ".proj.bias"])
 
 
+def unet_embedding(sd: State, ts: Tensor, labels: Optional[Tensor] = None, prefix: str = "predictor") -> Tensor:
+    """The conditioning vector every ResBlock's FiLM reads (unet.py:133-135): time_embed_extra(time_embed(ts)) [+ class_embed]."""
+    p = prefix
+    emb = time_embedding(ts, sd, p + ".time_embed")
+    emb = F.linear(F.gelu(emb), sd[p + ".time_embed_extra.1.weight"], sd[p + ".time_embed_extra.1.bias"])
+    if labels is not None:
+        emb = emb + F.embedding(labels, sd[p + ".class_embed.weight"])
+    return emb
+
+
 def unet_predictor(
     sd: State,
     base: int,
@@ -155,10 +165,7 @@ def unet_predictor(
     assert (cond is None) == (not has_cond), "must provide cond iff conditional"
     specs = predictor_block_specs(base)
 
-    emb = time_embedding(ts, sd, p + ".time_embed")
-    emb = F.linear(F.gelu(emb), sd[p + ".time_embed_extra.1.weight"], sd[p + ".time_embed_extra.1.bias"])
-    if labels is not None:
-        emb = emb + F.embedding(labels, sd[p + ".class_embed.weight"])
+    emb = unet_embedding(sd, ts, labels, p)
 
     h = F.conv1d(x, sd[p + ".in_conv.weight"], sd[p + ".in_conv.bias"], padding=1)
     if cond is not None:
@@ -401,3 +408,33 @@ def vqvae_decode(
         lambda xs, ts: unet_predictor(sd, base, xs, ts, cond=cond, labels=labels),
         steps, noises, constrain=constrain, cond_fn=cond_fn,
     )
+
+
+def vqvae_decode_uncond_guidance(
+    sd: State,
+    base: int,
+    schedule: str,
+    codes: Tensor,
+    labels: Tensor,
+    steps: int,
+    x_T: Tensor,
+    noises: List[Tensor],
+    constrain: bool = False,
+    label_scale: float = 0.0,
+    vq_scale: float = 0.0,
+) -> Tensor:
+    """VQVAE.decode_uncond_guidance (vq_vae.py:147-220) with both guidance scales on (the only configuration in which
+    the reference's always-tripled batch lines up, vq_vae.py:188-203): rows [conditional | codes zeroed | label 0],
+    labels offset by one (label 0 is the unconditional label), pred = base + s_vq (base - no_vq) + s_label (base - no_label)."""
+    assert vq_scale and label_scale and labels is not None
+    cond = vq_embed(sd["vq.dictionary"], codes) if codes.dim() == 2 else codes
+    n = cond.shape[0]
+    cond3 = torch.cat([cond, torch.zeros_like(cond), cond], dim=0)
+    lab3 = torch.cat([labels + 1, labels + 1, torch.zeros_like(labels)], dim=0)
+
+    def pred_fn(xs, ts):
+        outs = unet_predictor(sd, base, torch.cat([xs] * 3, dim=0), torch.cat([ts] * 3, dim=0), cond=cond3, labels=lab3)
+        b = outs[:n]
+        return b + vq_scale * (b - outs[n:2 * n]) + label_scale * (b - outs[2 * n:])
+
+    return ddpm_sample(schedule, x_T, pred_fn, steps, noises, constrain=constrain)

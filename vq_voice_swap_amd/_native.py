@@ -18,9 +18,10 @@ LIB_PATH = os.environ.get("VQVS_LIB_PATH") or os.path.join(_HERE, "libvqvs_hip.s
 CSRC = os.path.join(_HERE, "csrc")
 
 KIND_PREDICTOR, KIND_ENCODER, KIND_RESBLOCK, KIND_CLASSIFIER, KIND_ENCPRED = 0, 1, 2, 3, 4
-PREC_F32, PREC_BF16 = 0, 1
+PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
 DDPM_SIGMA_LARGE, DDPM_CONSTRAIN = 1, 2
-PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "float32": PREC_F32, "bf16": PREC_BF16, "bfloat16": PREC_BF16}
+PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "float32": PREC_F32, "bf16": PREC_BF16, "bfloat16": PREC_BF16,
+              "fp16": PREC_F16, "f16": PREC_F16, "float16": PREC_F16, "half": PREC_F16}
 
 
 class Cfg(C.Structure):
@@ -49,7 +50,7 @@ EXPORTS = [
     "vqvs_unet_forward", "vqvs_encoder_forward", "vqvs_resblock_forward", "vqvs_classifier_forward",
     "vqvs_classifier_guidance", "vqvs_encpred_forward", "vqvs_encpred_guidance", "vqvs_ddpm_step", "vqvs_ddpm_mean",
     "vqvs_ddpm_guided_eps", "vqvs_randn", "vqvs_vq_argmin", "vqvs_vq_embed", "vqvs_debug_tap_count",
-    "vqvs_debug_tap_info", "vqvs_debug_read_tap", "vqvs_forward_kernel_count", "vqvs_forward_model_bytes",
+    "vqvs_debug_tap_info", "vqvs_debug_read_tap", "vqvs_debug_read_embedding", "vqvs_forward_kernel_count", "vqvs_forward_model_bytes",
     "vqvs_forward_flops", "vqvs_set_profiling", "vqvs_op_info", "vqvs_op_desc", "vqvs_profile_read", "vqvs_last_error", "vqvs_version",
 ]
 
@@ -109,6 +110,7 @@ def lib():
     L.vqvs_debug_tap_count.argtypes = [vp]
     L.vqvs_debug_tap_info.argtypes = [vp, i32, C.c_char_p, i32, C.POINTER(i32), C.POINTER(i32)]
     L.vqvs_debug_read_tap.argtypes = [vp, i32, i32, i32, vp]
+    L.vqvs_debug_read_embedding.argtypes = [vp, i32, vp]
     L.vqvs_forward_kernel_count.argtypes = [vp]
     L.vqvs_forward_model_bytes.argtypes = [vp, i32, i32]
     L.vqvs_forward_model_bytes.restype = i64
@@ -258,6 +260,16 @@ class Handle:
             check(L.vqvs_debug_tap_info(self._h, i, name, 256, C.byref(ch), C.byref(ls)))
             out.append((name.value.decode(), ch.value, ls.value))
         return out
+
+    def read_embedding(self, B: int):
+        """Conditioning vector [B, 4*base] of the last forward (time embedding [+ class embedding])."""
+        import torch
+
+        out = torch.empty(B, 4 * self.cfg.base_channels, dtype=torch.float32)
+        r = lib().vqvs_debug_read_embedding(self._h, B, out.data_ptr())
+        if r < 0:
+            check(r)
+        return out[:, :r]
 
     def read_tap(self, i: int, B: int, T: int):
         import torch

@@ -304,11 +304,21 @@ int vqvs_debug_read_tap(vqvs_model* m, int i, int B, int T, float* h_out) {
   return e;
 }
 
+int vqvs_debug_read_embedding(vqvs_model* m, int B, float* h_out) {
+  if (!m || !h_out || B < 1 || B > m->cfg.max_batch) VQVS_FAIL(VQVS_ERR_ARG, "bad argument");
+  if (!m->emb_E) VQVS_FAIL(VQVS_ERR_STATE, "this model kind has no timestep embedding");
+  VQVS_HIP(hipSetDevice(m->device));
+  VQVS_HIP(hipDeviceSynchronize());
+  const float* src = reinterpret_cast<const float*>(m->d_arena + m->misc_off) + m->emb_misc_off;
+  VQVS_HIP(hipMemcpy(h_out, src, (size_t)B * m->emb_E * sizeof(float), hipMemcpyDeviceToHost));
+  return m->emb_E;
+}
+
 int vqvs_forward_kernel_count(const vqvs_model* m) { return m ? (int)m->ops.size() : 0; }
 
 int64_t vqvs_forward_model_bytes(const vqvs_model* m, int B, int T) {
   if (!m) return 0;
-  const double es = m->cfg.precision == VQVS_PREC_F32 ? 4.0 : 2.0;
+  const double es = m->cfg.precision == VQVS_PREC_F32 ? 4.0 : 2.0;  // BF16 and F16 store 2 bytes
   return (int64_t)((m->cost.elems_T * es + m->cost.bytes_f32) * (double)T * (double)B);
 }
 
@@ -336,7 +346,7 @@ int vqvs_op_info(const vqvs_model* m, int i, char* kind_out, int kind_cap, int64
     strncpy(kind_out, mt.kind.c_str(), kind_cap - 1);
     kind_out[kind_cap - 1] = 0;
   }
-  const double es = m->cfg.precision == VQVS_PREC_F32 ? 4.0 : 2.0;
+  const double es = m->cfg.precision == VQVS_PREC_F32 ? 4.0 : 2.0;  // BF16 and F16 store 2 bytes
   if (bytes_out) *bytes_out = (int64_t)((mt.elems_T * es + mt.bytes_f32) * (double)T * (double)B);
   if (flops_out) *flops_out = (int64_t)(mt.flops * (double)T * (double)B);
   return 0;

@@ -594,10 +594,7 @@ int launch_bw_act(const BwActArgs& a, int B, int precision, hipStream_t st) {
   if (a.C % 8 || opr > 256 || 256 % opr) VQVS_FAIL(-1, "bw_act: unsupported C=%d", a.C);
   if (a.resize == BW_FROM_HALF && (a.L & 1)) VQVS_FAIL(-1, "bw_act: avg-pool backward needs an even length");
   dim3 grid((a.L + STAT_TILE - 1) / STAT_TILE, B);
-  if (precision == 0)
-    hipLaunchKernelGGL(bw_act_kernel<float>, grid, dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL(bw_act_kernel<bf16_t>, grid, dim3(256), 0, st, a);
+  VQVS_BY_PRECISION(precision, hipLaunchKernelGGL(bw_act_kernel<T>, grid, dim3(256), 0, st, a));
   VQVS_HIP(hipGetLastError());
   return 0;
 }
@@ -613,10 +610,7 @@ int launch_bw_affine(const BwAffineArgs& a, int B, int precision, hipStream_t st
   if (a.C % 8) VQVS_FAIL(-1, "bw_affine: unsupported C=%d", a.C);
   const long long items = (long long)a.L * (a.C / 8);
   dim3 grid((unsigned)((items + 255) / 256), B);
-  if (precision == 0)
-    hipLaunchKernelGGL(bw_affine_kernel<float>, grid, dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL(bw_affine_kernel<bf16_t>, grid, dim3(256), 0, st, a);
+  VQVS_BY_PRECISION(precision, hipLaunchKernelGGL(bw_affine_kernel<T>, grid, dim3(256), 0, st, a));
   VQVS_HIP(hipGetLastError());
   return 0;
 }
@@ -625,10 +619,7 @@ int launch_in_conv_bw(const InConvBwArgs& a, int B, int precision, hipStream_t s
   const int opr = a.C / 8;
   if (a.C % 8 || opr > 64 || (opr & (opr - 1))) VQVS_FAIL(-1, "in_conv_bw: unsupported C=%d", a.C);
   dim3 grid((a.T + STAT_TILE - 1) / STAT_TILE, B);
-  if (precision == 0)
-    hipLaunchKernelGGL(in_conv_bw_kernel<float>, grid, dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL(in_conv_bw_kernel<bf16_t>, grid, dim3(256), 0, st, a);
+  VQVS_BY_PRECISION(precision, hipLaunchKernelGGL(in_conv_bw_kernel<T>, grid, dim3(256), 0, st, a));
   VQVS_HIP(hipGetLastError());
   return 0;
 }
@@ -637,10 +628,7 @@ int launch_bw_add(const void* x, const void* y, void* out, long long n, int prec
   if (n % 8) VQVS_FAIL(-1, "bw_add: element count must be a multiple of 8");
   const long long n8 = n / 8;
   dim3 grid((unsigned)((n8 + 255) / 256));
-  if (precision == 0)
-    hipLaunchKernelGGL(bw_add_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)y, (float*)out, n8);
-  else
-    hipLaunchKernelGGL(bw_add_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)y, (bf16_t*)out, n8);
+  VQVS_BY_PRECISION(precision, hipLaunchKernelGGL(bw_add_kernel<T>, grid, dim3(256), 0, st, (const T*)x, (const T*)y, (T*)out, n8));
   VQVS_HIP(hipGetLastError());
   return 0;
 }
@@ -650,20 +638,14 @@ int launch_enc_head(const EncHeadArgs& a, int B, int precision, hipStream_t st) 
   if (lds > 150 * 1024) VQVS_FAIL(-1, "encoder-predictor head: num_latents=%d needs %zu bytes of LDS (max 150 KB)", a.D, lds);
   if (a.T1 * a.rate != a.T) VQVS_FAIL(-1, "encoder-predictor head: T=%d is not %d x %d", a.T, a.T1, a.rate);
   dim3 grid((a.T1 + EH_POS - 1) / EH_POS, B);
-  static bool attr_done[2] = {false, false};
-  if (precision == 0) {
-    if (!attr_done[0]) {
-      VQVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_head_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-      attr_done[0] = true;
+  static bool attr_done[3] = {false, false, false};
+  VQVS_BY_PRECISION(precision, {
+    if (!attr_done[precision]) {
+      VQVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_head_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      attr_done[precision] = true;
     }
-    hipLaunchKernelGGL(enc_head_kernel<float>, grid, dim3(256), lds, st, a);
-  } else {
-    if (!attr_done[1]) {
-      VQVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_head_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-      attr_done[1] = true;
-    }
-    hipLaunchKernelGGL(enc_head_kernel<bf16_t>, grid, dim3(256), lds, st, a);
-  }
+    hipLaunchKernelGGL(enc_head_kernel<T>, grid, dim3(256), lds, st, a);
+  });
   VQVS_HIP(hipGetLastError());
   return 0;
 }
@@ -673,20 +655,14 @@ int launch_cls_head(const HeadArgs& a, int B, int precision, hipStream_t st) {
   if (a.groups > HEAD_NT) VQVS_FAIL(-1, "classifier head: too many groups");
   const size_t lds = head_lds_floats(a) * 4;
   if (lds > 150 * 1024) VQVS_FAIL(-1, "classifier head: %zu bytes of LDS needed (sequence too long: L=%d)", lds, a.L);
-  static bool attr_done[2] = {false, false};
-  if (precision == 0) {
-    if (!attr_done[0]) {
-      VQVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&cls_head_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-      attr_done[0] = true;
+  static bool attr_done[3] = {false, false, false};
+  VQVS_BY_PRECISION(precision, {
+    if (!attr_done[precision]) {
+      VQVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&cls_head_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      attr_done[precision] = true;
     }
-    hipLaunchKernelGGL(cls_head_kernel<float>, dim3(B), dim3(HEAD_NT), lds, st, a);
-  } else {
-    if (!attr_done[1]) {
-      VQVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&cls_head_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-      attr_done[1] = true;
-    }
-    hipLaunchKernelGGL(cls_head_kernel<bf16_t>, dim3(B), dim3(HEAD_NT), lds, st, a);
-  }
+    hipLaunchKernelGGL(cls_head_kernel<T>, dim3(B), dim3(HEAD_NT), lds, st, a);
+  });
   VQVS_HIP(hipGetLastError());
   return 0;
 }

@@ -29,6 +29,8 @@ void set_error(const std::string& msg);
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half_t;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -81,13 +83,17 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 splat2(float x) { return f32x2{x, x}; }
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 
-// EXACT = true : the A&S 7.1.28 form above, packed (|gelu error| <= 8.7e-7) -- VQVS_PREC_F32.
-// EXACT = false: v * (0.5 + vc*P(vc^2)), vc = clamp(v, -4, 4), P = degree-6 minimax fit of
-//                (Phi(v) - 0.5)/v; max |gelu error| = 5.7e-4 on [-8, 8], below the bf16 rounding of
-//                the stored result (2^-9 relative) -- VQVS_PREC_BF16.  No transcendental.
-template <bool EXACT>
+// GELU quality levels of the fused prologues (Q):
+//   GELU_EXACT : the A&S 7.1.28 form above, packed (|gelu error| <= 8.7e-7)                       -- VQVS_PREC_F32
+//   GELU_POLY6 : v * (0.5 + vc*P(vc^2)), vc = clamp(v, -4, 4), P = degree-6 minimax fit of (Phi(v) - 0.5)/v;
+//                max |gelu error| = 5.7e-4 on [-8, 8], below the bf16 rounding of the stored result -- VQVS_PREC_BF16
+//   GELU_POLY7 : the same form with a degree-7 fit: |gelu error| <= 4.4e-5 on [-4, 4] (<= 3.4e-4 on [-8, 8], i.e.
+//                3.2e-5 relative on the positive tail), below the fp16 rounding of O(1) results (2^-12) -- VQVS_PREC_F16
+// No transcendental in the polynomial forms.
+enum { GELU_EXACT = 0, GELU_POLY6 = 1, GELU_POLY7 = 2 };
+template <int Q>
 __device__ __forceinline__ f32x2 gelu2(f32x2 v) {
-  if constexpr (EXACT) {
+  if constexpr (Q == GELU_EXACT) {
     f32x2 z;
     z[0] = fabsf(v[0]);
     z[1] = fabsf(v[1]);
@@ -111,15 +117,30 @@ __device__ __forceinline__ f32x2 gelu2(f32x2 v) {
     vc[0] = __builtin_amdgcn_fmed3f(v[0], -4.0f, 4.0f);
     vc[1] = __builtin_amdgcn_fmed3f(v[1], -4.0f, 4.0f);
     const f32x2 w = vc * vc;
-    f32x2 p = fma2(splat2(2.81608722e-08f), w, splat2(-1.89188380e-06f));
-    p = fma2(p, w, splat2(5.41903041e-05f));
-    p = fma2(p, w, splat2(-8.78980255e-04f));
-    p = fma2(p, w, splat2(9.11294959e-03f));
-    p = fma2(p, w, splat2(-6.53883549e-02f));
-    p = fma2(p, w, splat2(3.98526915e-01f));
-    return v * fma2(vc, p, splat2(0.5f));  // Phi~(-4) = -7e-5 is not clamped: |error| <= 5.7e-4 on [-8, 8]
+    f32x2 p;
+    if constexpr (Q == GELU_POLY6) {
+      p = fma2(splat2(2.81608722e-08f), w, splat2(-1.89188380e-06f));
+      p = fma2(p, w, splat2(5.41903041e-05f));
+      p = fma2(p, w, splat2(-8.78980255e-04f));
+      p = fma2(p, w, splat2(9.11294959e-03f));
+      p = fma2(p, w, splat2(-6.53883549e-02f));
+      p = fma2(p, w, splat2(3.98526915e-01f));
+    } else {
+      p = fma2(splat2(-1.301278171e-09f), w, splat2(1.041951057e-07f));
+      p = fma2(p, w, splat2(-3.657111166e-06f));
+      p = fma2(p, w, splat2(7.485478930e-05f));
+      p = fma2(p, w, splat2(-1.006488756e-03f));
+      p = fma2(p, w, splat2(9.505392772e-03f));
+      p = fma2(p, w, splat2(-6.588783436e-02f));
+      p = fma2(p, w, splat2(3.986733897e-01f));
+    }
+    return v * fma2(vc, p, splat2(0.5f));  // Phi~(-4) = -7e-5 is not clamped
   }
 }
+template <typename T> struct GeluQ;  // quality level that goes with an activation storage type
+template <> struct GeluQ<float> { static constexpr int q = GELU_EXACT; };
+template <> struct GeluQ<bf16_t> { static constexpr int q = GELU_POLY6; };
+template <> struct GeluQ<half_t> { static constexpr int q = GELU_POLY7; };
 
 // element load/store of 8 consecutive channels as fp32, for both activation storage types
 template <typename T>
@@ -148,6 +169,33 @@ struct Elem<bf16_t> {
     *reinterpret_cast<bf16x8*>(p) = __builtin_convertvector(v, bf16x8);
   }
 };
+
+template <>
+struct Elem<half_t> {
+  static constexpr int BYTES = 2;
+  __device__ static __forceinline__ f32x8 load8(const half_t* p) {
+    const f16x8 a = *reinterpret_cast<const f16x8*>(p);
+    return __builtin_convertvector(a, f32x8);
+  }
+  __device__ static __forceinline__ void store8(half_t* p, f32x8 v) {
+    *reinterpret_cast<f16x8*>(p) = __builtin_convertvector(v, f16x8);
+  }
+};
+
+// one of three kernel instantiations by the model's precision (VQVS_PREC_*): F32 -> float, BF16 -> bf16_t, F16 -> half_t
+#define VQVS_BY_PRECISION(precision, CALL) \
+  do {                                      \
+    if ((precision) == 0) {                 \
+      using T = float;                      \
+      CALL;                                 \
+    } else if ((precision) == 1) {          \
+      using T = ::vqvs::bf16_t;             \
+      CALL;                                 \
+    } else {                                \
+      using T = ::vqvs::half_t;             \
+      CALL;                                 \
+    }                                       \
+  } while (0)
 
 __device__ __forceinline__ f32x8 f32x8_zero() { return f32x8{0, 0, 0, 0, 0, 0, 0, 0}; }
 

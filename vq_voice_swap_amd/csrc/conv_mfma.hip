@@ -48,7 +48,14 @@ constexpr int ROWB = 80;  // LDS bytes per 32-channel row (64 data + 16 pad)
 template <int HALO, int TT>
 constexpr int act_bytes() { return (TT + HALO) * ROWB; }
 
-template <bool X3>
+// MFMA operand element type that goes with an activation storage type: fp32 storage is split into two bf16 planes,
+// 2-byte storage types are their own operand type (raw segments reach LDS as untouched bits).
+template <typename T> struct Op { typedef bf16x8 v8; };
+template <> struct Op<half_t> { typedef f16x8 v8; };
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+
+template <bool X3, typename V8>
 __device__ __forceinline__ void put_row(char* act_hi, char* act_lo, int off, f32x8 v) {
   if constexpr (X3) {
     bf16x8 hi, lo;
@@ -56,16 +63,16 @@ __device__ __forceinline__ void put_row(char* act_hi, char* act_lo, int off, f32
     *reinterpret_cast<bf16x8*>(act_hi + off) = hi;
     *reinterpret_cast<bf16x8*>(act_lo + off) = lo;
   } else {
-    *reinterpret_cast<bf16x8*>(act_hi + off) = __builtin_convertvector(v, bf16x8);
+    *reinterpret_cast<V8*>(act_hi + off) = __builtin_convertvector(v, V8);
   }
 }
 
-template <bool EXACT>
+template <int GQ>
 __device__ __forceinline__ f32x8 affine_gelu(f32x8 v, const f32x8& sc, const f32x8& sh) {
   f32x8 r;
 #pragma unroll
   for (int j = 0; j < 8; j += 2) {
-    const f32x2 g = gelu2<EXACT>(fma2(f32x2{v[j], v[j + 1]}, f32x2{sc[j], sc[j + 1]}, f32x2{sh[j], sh[j + 1]}));
+    const f32x2 g = gelu2<GQ>(fma2(f32x2{v[j], v[j + 1]}, f32x2{sc[j], sc[j + 1]}, f32x2{sh[j], sh[j + 1]}));
     r[j] = g[0];
     r[j + 1] = g[1];
   }
@@ -92,6 +99,11 @@ template <> struct Raw8<bf16_t> {
   u32x4 a;
   __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, int off) { a = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0); }
   __device__ __forceinline__ f32x8 get() const { return __builtin_convertvector(__builtin_bit_cast(bf16x8, a), f32x8); }
+};
+template <> struct Raw8<half_t> {
+  u32x4 a;
+  __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, int off) { a = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0); }
+  __device__ __forceinline__ f32x8 get() const { return __builtin_convertvector(__builtin_bit_cast(f16x8, a), f32x8); }
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, long long bytes) {
@@ -134,6 +146,8 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
   constexpr int NWV = (3 * CT * 4 + NTH - 1) / NTH;  // 16-byte weight pieces per thread per chunk
   constexpr int PLANES = X3 ? 2 : 1;
   constexpr int BUF_BYTES = PLANES * (ACT_BYTES + W_BYTES);
+  constexpr int GQ = GeluQ<T>::q;
+  typedef typename Op<T>::v8 V8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
 #ifdef VQVS_TIMING
@@ -322,8 +336,8 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
             *reinterpret_cast<u32x4*>(act_hi + act_lds[i]) = ra[i].a;
           } else {
             f32x8 v = ra[i].get();
-            if (g.xform) v = affine_gelu<X3>(v, sc, sh);
-            put_row<X3>(act_hi, act_lo, act_lds[i], v);
+            if (g.xform) v = affine_gelu<GQ>(v, sc, sh);
+            put_row<X3, V8>(act_hi, act_lo, act_lds[i], v);
           }
         }
       }
@@ -333,7 +347,7 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
         for (int i = 0; i < NPF; ++i) {
           const int r = (tid >> 2) + (NTH / 4) * i;
           const int tm = g.base_time + r;
-          if (r < g.nrows && (tm < 0 || tm >= g.row_bound)) put_row<X3>(act_hi, act_lo, act_lds[i], f32x8_zero());
+          if (r < g.nrows && (tm < 0 || tm >= g.row_bound)) put_row<X3, V8>(act_hi, act_lo, act_lds[i], f32x8_zero());
         }
       }
     } else {  // avg-pool segments (8 of 130 convs): staged synchronously, two source rows per LDS row
@@ -345,10 +359,10 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
           const T* p = src_c + (size_t)(2 * tm) * g.Csrc;
           f32x8 v0 = Elem<T>::load8(p);
           f32x8 v1 = Elem<T>::load8(p + g.Csrc);
-          if (g.xform) { v0 = affine_gelu<X3>(v0, sc, sh); v1 = affine_gelu<X3>(v1, sc, sh); }
+          if (g.xform) { v0 = affine_gelu<GQ>(v0, sc, sh); v1 = affine_gelu<GQ>(v1, sc, sh); }
           v = (v0 + v1) * 0.5f;
         }
-        put_row<X3>(act_hi, act_lo, r * ROWB + oct * 16, v);
+        put_row<X3, V8>(act_hi, act_lo, r * ROWB + oct * 16, v);
       }
     }
     // weights: every piece is written (1-tap segments leave garbage in the unused tap rows)
@@ -381,28 +395,28 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
       const int wrow = k * CT;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 ah[WM], al[WM], bh[WN], bl[WN];
+        V8 ah[WM], al[WM], bh[WN], bl[WN];
 #pragma unroll
         for (int mt = 0; mt < WM; ++mt) {
           const int ad = frag_addr(ar[mt], ks * 2 + ohalf);
-          ah[mt] = *reinterpret_cast<const bf16x8*>(act_hi + ad);
-          if constexpr (X3) al[mt] = *reinterpret_cast<const bf16x8*>(act_lo + ad);
+          ah[mt] = *reinterpret_cast<const V8*>(act_hi + ad);
+          if constexpr (X3) al[mt] = *reinterpret_cast<const V8*>(act_lo + ad);
         }
 #pragma unroll
         for (int nt = 0; nt < WN; ++nt) {
           const int ad = frag_addr(wrow + (wvn * WN + nt) * 32 + l31, ks * 2 + ohalf);
-          bh[nt] = *reinterpret_cast<const bf16x8*>(w_hi + ad);
-          if constexpr (X3) bl[nt] = *reinterpret_cast<const bf16x8*>(w_lo + ad);
+          bh[nt] = *reinterpret_cast<const V8*>(w_hi + ad);
+          if constexpr (X3) bl[nt] = *reinterpret_cast<const V8*>(w_lo + ad);
         }
 #pragma unroll
         for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
           for (int nt = 0; nt < WN; ++nt) {
             if constexpr (X3) {
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = mfma32(al[mt], bh[nt], acc[mt][nt]);
+              acc[mt][nt] = mfma32(ah[mt], bl[nt], acc[mt][nt]);
             }
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = mfma32(ah[mt], bh[nt], acc[mt][nt]);
           }
       }
     }
@@ -691,6 +705,7 @@ int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st) {
   const bool big_halo = dmax > 2;
   if (a.tile_rows != conv_tile_rows(dmax, a.Cout, precision)) VQVS_FAIL(-1, "conv: tile_rows %d does not match dilation %d", a.tile_rows, dmax);
   if (precision == 0) return launch_p<float, true>(a, B, st, wide, big_halo, dmax);
+  if (precision == 2) return launch_p<half_t, false>(a, B, st, wide, big_halo, dmax);
   return launch_p<bf16_t, false>(a, B, st, wide, big_halo, dmax);
 }
 

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void in_conv_kernel(const InConvArgs a) {
 // ------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void out_conv_kernel(const OutConvArgs a) {
-  constexpr bool EXACT = sizeof(T) == 4;
+  constexpr int GQ = GeluQ<T>::q;
   __shared__ float y[3][STAT_TILE + 2];
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void out_conv_kernel(const OutConvArgs a) {
       const f32x8 v = Elem<T>::load8(xb + (size_t)t * a.C);
 #pragma unroll
       for (int j = 0; j < 8; j += 2) {
-        const f32x2 g = gelu2<EXACT>(fma2(f32x2{v[j], v[j + 1]}, f32x2{sc[j], sc[j + 1]}, f32x2{sh[j], sh[j + 1]}));
+        const f32x2 g = gelu2<GQ>(fma2(f32x2{v[j], v[j + 1]}, f32x2{sc[j], sc[j + 1]}, f32x2{sh[j], sh[j + 1]}));
         p0 = fmaf(w0[j + 1], g[1], fmaf(w0[j], g[0], p0));
         p1 = fmaf(w1[j + 1], g[1], fmaf(w1[j], g[0], p1));
         p2 = fmaf(w2[j + 1], g[1], fmaf(w2[j], g[0], p2));
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(128) void film_kernel(const FilmArgs a, int B) {
 // ------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void xform_kernel(const XformArgs a) {
-  constexpr bool EXACT = sizeof(T) == 4;
+  constexpr int GQ = GeluQ<T>::q;
   const int b = blockIdx.y;
   const int opr = a.C >> 3;
   const long long item = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void xform_kernel(const XformArgs a) {
     f32x8 r;
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {
-      const f32x2 g = gelu2<EXACT>(fma2(f32x2{v[j], v[j + 1]}, f32x2{sc[j], sc[j + 1]}, f32x2{sh[j], sh[j + 1]}));
+      const f32x2 g = gelu2<GQ>(fma2(f32x2{v[j], v[j + 1]}, f32x2{sc[j], sc[j + 1]}, f32x2{sh[j], sh[j + 1]}));
       r[j] = g[0];
       r[j + 1] = g[1];
     }
@@ -416,10 +416,7 @@ __global__ __launch_bounds__(256) void ntc_stats_kernel(const T* in, float* stat
 int launch_in_conv(const InConvArgs& a, int B, int precision, hipStream_t st) {
   if (a.C % 8 || a.C > 256 || (256 % (a.C / 8)) != 0) VQVS_FAIL(-1, "in_conv: unsupported C=%d", a.C);
   dim3 grid((a.T + STAT_TILE - 1) / STAT_TILE, B);
-  if (precision == 0)
-    hipLaunchKernelGGL(in_conv_kernel<float>, grid, dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL(in_conv_kernel<bf16_t>, grid, dim3(256), 0, st, a);
+  VQVS_BY_PRECISION(precision, hipLaunchKernelGGL(in_conv_kernel<T>, grid, dim3(256), 0, st, a));
   VQVS_HIP(hipGetLastError());
   return 0;
 }
@@ -428,10 +425,7 @@ int launch_out_conv(const OutConvArgs& a, int B, int precision, hipStream_t st) 
   const int opr = a.C / 8;
   if (a.C % 8 || opr > 64 || (opr & (opr - 1))) VQVS_FAIL(-1, "out_conv: unsupported C=%d", a.C);
   dim3 grid((a.L + STAT_TILE - 1) / STAT_TILE, B);
-  if (precision == 0)
-    hipLaunchKernelGGL(out_conv_kernel<float>, grid, dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL(out_conv_kernel<bf16_t>, grid, dim3(256), 0, st, a);
+  VQVS_BY_PRECISION(precision, hipLaunchKernelGGL(out_conv_kernel<T>, grid, dim3(256), 0, st, a));
   VQVS_HIP(hipGetLastError());
   return 0;
 }
@@ -470,33 +464,24 @@ int launch_xform(const XformArgs& a, int B, int precision, hipStream_t st) {
   if (a.C % 8) VQVS_FAIL(-1, "xform: unsupported C=%d", a.C);
   const long long items = (long long)a.Lout * (a.C / 8);
   dim3 grid((unsigned)((items + 255) / 256), B);
-  if (precision == 0)
-    hipLaunchKernelGGL(xform_kernel<float>, grid, dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL(xform_kernel<bf16_t>, grid, dim3(256), 0, st, a);
+  VQVS_BY_PRECISION(precision, hipLaunchKernelGGL(xform_kernel<T>, grid, dim3(256), 0, st, a));
   VQVS_HIP(hipGetLastError());
   return 0;
 }
 
 int launch_nct_to_ntc(const float* in, void* out, float* stats, int B, int C, int L, int ntiles, int precision, hipStream_t st) {
   dim3 grid((L + 31) / 32, (C + 31) / 32, B);
-  if (precision == 0) {
-    hipLaunchKernelGGL(nct_to_ntc_kernel<float>, grid, dim3(256), 0, st, in, (float*)out, C, L);
-    if (stats) hipLaunchKernelGGL(ntc_stats_kernel<float>, dim3(ntiles, B), dim3(256), 0, st, (const float*)out, stats, C, L, ntiles);
-  } else {
-    hipLaunchKernelGGL(nct_to_ntc_kernel<bf16_t>, grid, dim3(256), 0, st, in, (bf16_t*)out, C, L);
-    if (stats) hipLaunchKernelGGL(ntc_stats_kernel<bf16_t>, dim3(ntiles, B), dim3(256), 0, st, (const bf16_t*)out, stats, C, L, ntiles);
-  }
+  VQVS_BY_PRECISION(precision, {
+    hipLaunchKernelGGL(nct_to_ntc_kernel<T>, grid, dim3(256), 0, st, in, (T*)out, C, L);
+    if (stats) hipLaunchKernelGGL(ntc_stats_kernel<T>, dim3(ntiles, B), dim3(256), 0, st, (const T*)out, stats, C, L, ntiles);
+  });
   VQVS_HIP(hipGetLastError());
   return 0;
 }
 
 int launch_ntc_to_nct(const void* in, float* out, int B, int C, int L, int in_precision, hipStream_t st) {
   dim3 grid((L + 31) / 32, (C + 31) / 32, B);
-  if (in_precision == 0)
-    hipLaunchKernelGGL(ntc_to_nct_kernel<float>, grid, dim3(256), 0, st, (const float*)in, out, C, L);
-  else
-    hipLaunchKernelGGL(ntc_to_nct_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)in, out, C, L);
+  VQVS_BY_PRECISION(in_precision, hipLaunchKernelGGL(ntc_to_nct_kernel<T>, grid, dim3(256), 0, st, (const T*)in, out, C, L));
   VQVS_HIP(hipGetLastError());
   return 0;
 }

@@ -112,6 +112,24 @@ uint16_t f2bf(float f) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return (uint16_t)(u >> 16);
 }
+// float32 -> IEEE binary16, round to nearest even (VQVS_PREC_F16 packs the convolution weights in the operand type)
+uint16_t f2h(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  const uint32_t sign = (u >> 16) & 0x8000u;
+  const uint32_t a = u & 0x7fffffffu;
+  if (a >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (a > 0x7f800000u ? 0x200u : 0u));
+  if (a >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);  // >= 65520 rounds to infinity
+  if (a < 0x33000001u) return (uint16_t)sign;                // < 2^-25 rounds to zero
+  int e = (int)(a >> 23) - 127;
+  uint32_t m = (a & 0x7fffffu) | 0x800000u;
+  int shift = e < -14 ? (13 + (-14 - e)) : 13;               // subnormal results lose further bits
+  uint32_t r = m >> shift;
+  const uint32_t rem = m & ((1u << shift) - 1), half = 1u << (shift - 1);
+  if (rem > half || (rem == half && (r & 1u))) ++r;
+  if (e < -14) return (uint16_t)(sign | r);                  // r may carry into the smallest normal: still correct bits
+  return (uint16_t)(sign | (((uint32_t)(e + 15) << 10) + (r - 0x400u)));
+}
 float bf2f(uint16_t h) {
   const uint32_t u = (uint32_t)h << 16;
   float f;
@@ -132,6 +150,8 @@ struct Blob {
 // conv weights in MFMA B-operand order: [segment][chunk of 32 ci][tap][Cout][32 ci]
 struct PackedConv {
   std::vector<uint16_t> hi, lo;
+  bool f16 = false;  // VQVS_PREC_F16: `hi` holds binary16 bits, `lo` is unused
+  explicit PackedConv(int precision = VQVS_PREC_F32) : f16(precision == VQVS_PREC_F16) {}
   long long append(const float* W, int Cout, int Cin_total, int ktaps, int cb, int C) {
     const long long off = (long long)hi.size();
     for (int ch = 0; ch < C / 32; ++ch)
@@ -139,6 +159,10 @@ struct PackedConv {
         for (int co = 0; co < Cout; ++co)
           for (int j = 0; j < 32; ++j) {
             const float w = W[((size_t)co * Cin_total + cb + ch * 32 + j) * ktaps + k];
+            if (f16) {
+              hi.push_back(f2h(w));
+              continue;
+            }
             const uint16_t h = f2bf(w);
             hi.push_back(h);
             lo.push_back(f2bf(w - bf2f(h)));
@@ -400,7 +424,7 @@ class Builder {
     // conv 1
     TensorH h1 = new_tensor(cout, out_shift, false, true);
     {
-      PackedConv pk;
+      PackedConv pk(m_->cfg.precision);
       std::vector<SegSpec> segs;
       const float* W = P(pre + "pre_cond.2.weight");
       int cb = 0;
@@ -428,7 +452,7 @@ class Builder {
     // conv 2 + skip
     TensorH out = new_tensor(cout, out_shift, false, true);
     {
-      PackedConv pk;
+      PackedConv pk(m_->cfg.precision);
       std::vector<SegSpec> segs;
       const std::string c2 = pre + (cfg_dropout(m_->cfg) ? "post_cond.2" : "post_cond.1");
       const float* W = P(c2 + ".weight");
@@ -559,7 +583,7 @@ class Builder {
   // plain convolution of a raw tensor with transposed weights (no prologue, no statistics, zero bias)
   void add_conv_t(const TensorH& src, const float* W, int Cout_fwd, int Cin_fwd, int ktaps, int dil, const TensorH& out) {
     const std::vector<float> Wt = transpose_flip(W, Cout_fwd, Cin_fwd, ktaps);
-    PackedConv pk;
+    PackedConv pk(m_->cfg.precision);
     SegSpec g{src, 0, Cout_fwd, ktaps, dil, RESIZE_NONE, false, 0, 0, 0, 0};
     g.w_off = pk.append(Wt.data(), Cin_fwd, Cout_fwd, ktaps, 0, Cout_fwd);
     add_conv({g}, pk, std::vector<float>(Cin_fwd, 0.f), Cin_fwd, out, nullptr, 0);
@@ -758,7 +782,7 @@ int enumerate_params(const vqvs_cfg& c, std::vector<ParamDef>& out) {
 }
 
 static int check_cfg(const vqvs_cfg& c) {
-  if (c.precision != VQVS_PREC_F32 && c.precision != VQVS_PREC_BF16) VQVS_FAIL(VQVS_ERR_ARG, "bad precision %d", c.precision);
+  if (c.precision != VQVS_PREC_F32 && c.precision != VQVS_PREC_BF16 && c.precision != VQVS_PREC_F16) VQVS_FAIL(VQVS_ERR_ARG, "bad precision %d", c.precision);
   if (c.max_batch < 1 || c.max_T < 1) VQVS_FAIL(VQVS_ERR_ARG, "max_batch/max_T must be positive");
   if (c.kind == VQVS_KIND_RESBLOCK) {
     if (c.rb_cin % 32 || c.rb_cout % 32 || c.rb_cin < 32 || c.rb_cout < 32) VQVS_FAIL(VQVS_ERR_ARG, "resblock channels must be multiples of 32");
@@ -857,6 +881,8 @@ int build_model(vqvs_model* m, const float* const* hp) {
     const size_t ce = c.num_labels > 0 ? b.blob_f32(px + "class_embed.weight") : 0;
     const size_t emb_off = b.alloc_misc((size_t)c.max_batch * E);
     const size_t gemb_off = b.alloc_misc((size_t)c.max_batch * E);
+    m->emb_misc_off = emb_off;
+    m->emb_E = E;
     const int NL = c.num_labels;
     m->meta.push_back({"time_embed", "", 0, 0, 0});
     m->add_op([=](const RunCtx& r) -> int {
@@ -911,7 +937,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
         return launch_nct_to_ntc(r.cond, bp->act(ct.off), nullptr, r.B, CC, r.Lbase >> 8, 0, prec, r.st);
       });
       condp = b.new_tensor(base, 8, false, false);
-      PackedConv pk;
+      PackedConv pk(prec);
       Builder::SegSpec g{ct, 0, CC, 3, 1, RESIZE_NONE, false, 0, 0, 0, 0};
       g.w_off = pk.append(b.P(px + "cond_proj.weight"), base, CC, 3, 0, CC);
       const float* bb = b.P(px + "cond_proj.bias");
@@ -1003,7 +1029,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
       });
     } else {
       TensorH o = b.new_tensor(c.out_channels, 0, true, false);
-      PackedConv pk;
+      PackedConv pk(prec);
       Builder::SegSpec g{h, 0, base, 3, 1, RESIZE_NONE, true, ss, base, 0, 0};
       g.w_off = pk.append(b.P(px + "out.1.weight"), c.out_channels, base, 3, 0, base);
       const float* bb = b.P(px + "out.1.bias");
@@ -1092,6 +1118,8 @@ int build_model(vqvs_model* m, const float* const* hp) {
     const size_t w2 = b.blob_f32_transposed(b.P("stem.time_embed_extra.1.weight"), E, E), b2 = b.blob_f32("stem.time_embed_extra.1.bias");
     const size_t emb_off = b.alloc_misc((size_t)c.max_batch * E);
     const size_t gemb_off = b.alloc_misc((size_t)c.max_batch * E);
+    m->emb_misc_off = emb_off;
+    m->emb_E = E;
     m->meta.push_back({"time_embed", "", 0, 0, 0});
     m->add_op([=](const RunCtx& r) -> int {
       TimeEmbedArgs a{};
@@ -1261,7 +1289,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
     const size_t ss = b.alloc_ss(cur);
     b.add_gn({h}, "out.0.0", false, 0, 0, 0, ss);
     TensorH o = b.new_tensor(c.out_channels, 8, true, false);
-    PackedConv pk;
+    PackedConv pk(prec);
     Builder::SegSpec g{h, 0, cur, 3, 1, RESIZE_NONE, true, ss, cur, 0, 0};
     g.w_off = pk.append(b.P("out.1.weight"), c.out_channels, cur, 3, 0, cur);
     const float* bb = b.P("out.1.bias");

@@ -95,6 +95,8 @@ struct vqvs_model {
     double flops = 0;      // per clip per unit length
   } cost;
   int last_B = 0, last_L = 0;
+  size_t emb_misc_off = 0;  // conditioning vector [max_batch][emb_E] of the last forward (misc region, floats); emb_E = 0: none
+  int emb_E = 0;
   std::shared_ptr<void> keepalive;  // schedule builder (resolves arena/weight offsets for the ops)
 };
 

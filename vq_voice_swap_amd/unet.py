@@ -88,7 +88,7 @@ class _NativeModule(nn.Module):
 
     def set_precision(self, precision: str):
         if precision not in _native.PRECISIONS:
-            raise ValueError(f"unknown precision {precision!r}; use 'fp32' or 'bf16'")
+            raise ValueError(f"unknown precision {precision!r}; use 'fp32', 'fp16' or 'bf16'")
         self.precision = precision
         self.invalidate()
         return self
@@ -98,6 +98,7 @@ class _NativeModule(nn.Module):
             self._handle.close()
         self._handle = None
         self._handle_key = None
+        self.__dict__.pop("_token_tensors", None)
 
     def _apply(self, fn, *a, **k):
         self.invalidate()
@@ -114,15 +115,29 @@ class _NativeModule(nn.Module):
     def _cfg(self) -> _native.Cfg:
         raise NotImplementedError
 
+    def _weights_token(self):
+        """Changes whenever a parameter or buffer is written in place or replaced (`p.data.copy_`, optimizer steps,
+        `load_from_pretrained`, EMA copies): the device snapshot is rebuilt instead of silently running old weights
+        (the reference reads live parameters on every call)."""
+        ts = self.__dict__.get("_token_tensors")
+        if ts is None:  # the module tree is walked once per handle, not once per forward
+            ts = list(self.parameters()) + list(self.buffers())
+            self.__dict__["_token_tensors"] = ts
+        tok = 0
+        for t in ts:
+            tok = (tok * 1000003 + t._version * 8191 + t.data_ptr()) & 0xFFFFFFFFFFFF
+        return tok
+
     def handle(self, device: torch.device, B: int, T: int) -> _native.Handle:
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        key = (idx, self.precision, bool(self.debug_taps))
+        key = (idx, self.precision, bool(self.debug_taps), self._weights_token())
         h = self._handle
         if h is not None and self._handle_key == key and h.cfg.max_batch >= B and h.cfg.max_T >= T:
             return h
         if h is not None:
-            B = max(B, h.cfg.max_batch) if self._handle_key == key else B
-            T = max(T, h.cfg.max_T) if self._handle_key == key else T
+            same_shape_class = self._handle_key[:3] == key[:3]
+            B = max(B, h.cfg.max_batch) if same_shape_class else B
+            T = max(T, h.cfg.max_T) if same_shape_class else T
             self.invalidate()
         cfg = self._cfg()
         cfg.precision = _native.PRECISIONS[self.precision]
@@ -133,6 +148,37 @@ class _NativeModule(nn.Module):
         self._handle = _native.Handle(cfg, self.state_dict(), "", idx)
         self._handle_key = key
         return self._handle
+
+    # the ctypes handle cannot be pickled or deep-copied (EMA copies, torch.save(model)): drop it, the copy rebuilds its own
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        d["_handle"] = None
+        d["_handle_key"] = None
+        d.pop("_token_tensors", None)
+        return d
+
+    def __deepcopy__(self, memo):
+        import copy
+
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k == "_token_tensors":
+                continue
+            new.__dict__[k] = None if k in ("_handle", "_handle_key") else copy.deepcopy(v, memo)
+        return new
+
+    def _check_inference_only(self, *tensors):
+        """forward() detaches its inputs and ignores dropout: say so instead of silently returning no gradients."""
+        if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+            import warnings
+
+            warnings.warn("the gfx950 UNet path is inference-only: inputs are detached, no gradient flows through forward()",
+                          RuntimeWarning, stacklevel=3)
+        if self.training and getattr(self, "dropout", 0.0):
+            raise RuntimeError("the gfx950 UNet path does not implement dropout: call .eval() before sampling "
+                               "(the reference applies dropout only in training, unet.py:295-300)")
 
 
 class UNetPredictor(_NativeModule):
@@ -204,6 +250,7 @@ class UNetPredictor(_NativeModule):
         assert (labels is None) == (self.num_labels is None), "must provide labels if and only if model is class conditional"
         assert (cond is None) == (self.cond_channels is None), "must provide cond sequence if and only if model is conditional"
         _native.require_cuda(x, ts, cond, labels)
+        self._check_inference_only(x, cond)
         if x.dim() != 3 or x.shape[1] != self.in_channels:
             raise ValueError(f"expected x of shape [N, {self.in_channels}, T], got {tuple(x.shape)}")
         B, _, T = x.shape

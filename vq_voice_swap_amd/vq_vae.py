@@ -33,9 +33,11 @@ class VQVAE(DiffusionModel):
         self.encoder = encoder
         self.vq = VQ(self.cond_channels, dictionary_size)
 
-    def set_precision(self, precision: str):
+    def set_precision(self, precision: str, encoder_precision: str = "fp32"):
+        """Precision of the diffusion decoder; the encoder stays in the fp32 mode unless asked otherwise, because VQ code
+        indices have to be bit-exact (a 2-byte encoder flips near-tie codes: 23/500 in bf16) and it runs once per clip."""
         self.predictor.set_precision(precision)
-        self.encoder.set_precision(precision)
+        self.encoder.set_precision(encoder_precision)
         return self
 
     def encode(self, inputs: torch.Tensor) -> torch.Tensor:
