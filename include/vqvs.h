@@ -20,7 +20,7 @@
  *     it, thread-local).  Nothing here falls back to a CPU path.
  *   - a handle is not thread-safe (one scratch arena); different handles are
  *     independent.  The handle-less entry points (vqvs_ddpm_step with CONSTRAIN,
- *     vqvs_vq_argmin) share one small per-process scratch buffer: issue them from
+ *     vqvs_vq_argmin) share one small scratch buffer per device (it only grows): issue them from
  *     one thread and one stream at a time.  One process per GPU.
  */
 #ifndef VQVS_H

@@ -1,5 +1,6 @@
 """CPU-side checks: the C-ABI library loads and exports every declared symbol, the parameter table equals
 the reference's state-dict layout, checkpoints round-trip, error behaviour, sharding logic (gloo, world 2)."""
+import json
 import os
 import re
 import subprocess
@@ -130,3 +131,41 @@ def test_plain_c_client_of_the_abi(tmp_path, lib_built):
     table = _native.param_table(cfg)
     assert f"{len(table)} parameters" in out and "time_embed.proj.weight" in out
     assert f"total {sum(int(np.prod(s)) for _, s in table)} float32 values" in out
+
+
+def _run_bench(args, env_extra, timeout=300):
+    import subprocess
+
+    env = dict(os.environ, VQVS_BENCH_BACKEND="gloo", OMP_NUM_THREADS="2", **env_extra)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=env, timeout=timeout)
+
+
+def test_bench_gpus_n_launches_n_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment must start two ranks itself (re-exec under
+    torch.distributed.run) and only report when the process group really has two ranks.  Run here up to process-group
+    initialisation on gloo (`--init-only`); on a GPU box the same path continues into the RCCL benchmark."""
+    r = _run_bench(["--gpus", "2", "--init-only"], {})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out == {"init_only": True, "world_size": 2, "backend": "gloo", "allreduce_ok": True}
+
+
+def test_bench_refuses_world_size_mismatch():
+    """Launched with 2 ranks but asked to report 3 GPUs: no JSON line, non-zero exit."""
+    import subprocess
+
+    from bench import free_port
+
+    env = dict(os.environ, VQVS_BENCH_BACKEND="gloo", OMP_NUM_THREADS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "3", "--init-only"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], r.stdout
+    assert "refusing to report" in r.stderr

@@ -106,3 +106,37 @@ def test_vqvae_paths_match_reference(golden, lib_built):
     noises = [torch.randn(x_T.shape, generator=gen) for _ in range(5)]
     dec = ref_cpu.vqvae_decode(sd, 32, "exp", torch.from_numpy(z8["codes16"]), torch.from_numpy(z8["labels"]), 5, x_T, noises, constrain=True)
     assert (dec - torch.from_numpy(z8["x0"])).abs().max().item() <= 1e-5
+
+
+def test_time_embedding_matches_reference(golden, lib_built):
+    z = golden("f2_time_embed")
+    ts = torch.from_numpy(z["ts"])
+    for base in (32, 64):
+        sd = det_sd(predictor_cfg(base, labels=6), "predictor.")
+        emb = ref_cpu.unet_embedding(sd, ts, torch.from_numpy(z[f"c{base}.labels"]))
+        assert torch.equal(emb, torch.from_numpy(z[f"c{base}.emb"])), base
+
+
+def test_ddpm_previous_cos_matches_reference(golden):
+    z = golden("f5b_ddpm_previous_cos")
+    for i in range(5):
+        t, step = z[f"c{i}.t_step"]
+        x, eps, noise = (torch.from_numpy(z[f"c{i}.{k}"]) for k in ("x", "eps", "noise"))
+        ts = torch.tensor([t, t], dtype=torch.float32)
+        for mode, kw in (("plain", {}), ("sigma_large", dict(sigma_large=True)), ("constrain", dict(constrain=True))):
+            y = ref_cpu.ddpm_previous("cos", x, ts, float(step), eps, noise, **kw)
+            assert torch.equal(y, torch.from_numpy(z[f"c{i}.{mode}"])), (i, mode)
+
+
+def test_decode_uncond_guidance_matches_reference(golden, lib_built):
+    z = golden("f11_uncond_guidance")
+    sd = det_sd(predictor_cfg(32, cond=512, labels=5), "predictor.")
+    sd["vq.dictionary"] = seeded((512, 512), 77, 0.35)
+    steps = int(z["steps"])
+    x_T = seeded((2, 1, 2048), int(z["x_T_seed"]))
+    gen = torch.Generator().manual_seed(int(z["noise_seed"]))
+    noises = [torch.randn(x_T.shape, generator=gen) for _ in range(steps)]
+    vq_scale, label_scale = (float(v) for v in z["scales"])
+    dec = ref_cpu.vqvae_decode_uncond_guidance(sd, 32, "exp", torch.from_numpy(z["codes"]), torch.from_numpy(z["labels"]), steps, x_T, noises,
+                                               constrain=True, label_scale=label_scale, vq_scale=vq_scale)
+    assert (dec - torch.from_numpy(z["x0"])).abs().max().item() <= 1e-5

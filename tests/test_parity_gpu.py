@@ -1,9 +1,9 @@
 """Parity of the HIP path (through the C ABI) with the CPU oracle and the golden vectors, on a real MI355X.
 
-Tolerances (north_star): waveforms within 1e-3 RMS of the CPU reference in the fp32-storage mode
-("fp32": fp32 activations, 3-term bf16-split MFMA, fp32 accumulate); VQ code indices bit-exact.
-The bf16-storage throughput mode is checked against a relative bound (bf16 has 8 significant bits:
-per-tensor rounding 2^-9 accumulates over 130 convolutions to ~1e-2 on eps)."""
+Tolerances (north_star): waveforms within 1e-3 RMS of the CPU reference; VQ code indices bit-exact.  Two modes meet
+the waveform gate and are held to it here: "fp32" (fp32 activations, 3-term bf16-split MFMA: ~5e-6) and "fp16" (fp16
+activations and weights, f16 MFMA, fp32 statistics / accumulation: 3e-4 ... 8e-4, the benchmarked mode).  The bf16 mode
+(8 significant bits: ~1e-2 on eps, 2.6e-3 on waveforms) is outside the gate and only checked against a loose relative bound."""
 import numpy as np
 import pytest
 import torch
@@ -18,8 +18,10 @@ pytestmark = pytest.mark.gpu
 torch.set_num_threads(8)
 
 FP32_REL = 1e-4   # per-forward relative RMS bound in fp32 mode (measured ~2e-5)
+FP16_REL = 4e-3   # per-forward relative RMS bound on eps in fp16 mode (measured 1.3e-3 ... 1.6e-3; per ResBlock 4.5e-4)
 BF16_REL = 3e-2   # per-forward relative RMS bound in bf16 mode (measured ~1.3e-2)
-WAVE_RMS = 1e-3   # north_star gate on sampled waveforms (fp32 mode)
+WAVE_RMS = 1e-3   # north_star gate on sampled waveforms (fp32 AND fp16 modes)
+MODES = [("fp32", FP32_REL), ("fp16", FP16_REL), ("bf16", BF16_REL)]
 
 
 @pytest.fixture(scope="module")
@@ -34,7 +36,7 @@ def det_model(m):
     return m
 
 
-@pytest.mark.parametrize("prec,tol", [("fp32", FP32_REL), ("bf16", BF16_REL)])
+@pytest.mark.parametrize("prec,tol", MODES)
 def test_resblocks_vs_golden(golden, dev, prec, tol):
     z = golden("f1_resblocks")
     for name in sorted({k.split(".")[0] for k in z.files}):
@@ -76,8 +78,9 @@ def test_unet32_forward_and_every_block_vs_oracle(golden, dev):
     for i, (name, ch, ls) in enumerate(h.taps()):
         assert rel_rms(h.read_tap(i, 2, 64000), taps[name]) < FP32_REL, name
     model.predictor.debug_taps = False
-    model.set_precision("bf16")
-    assert rel_rms(model.predictor(x.to(dev), ts.to(dev)).cpu(), want) < BF16_REL
+    for prec, tol in MODES[1:]:
+        model.set_precision(prec)
+        assert rel_rms(model.predictor(x.to(dev), ts.to(dev)).cpu(), want) < tol, prec
 
 
 def test_forward_is_deterministic_and_batch_independent(dev):
@@ -142,6 +145,11 @@ def test_sampler_end_to_end_vs_golden(golden, dev, tag, steps, constrain, sq):
         assert rms(got - want) < WAVE_RMS  # bounded waveform: absolute gate
     else:
         assert rel_rms(got, want) < WAVE_RMS  # untrained weights blow x up to RMS ~455: relative gate
+    # the benchmarked mode is held to the same gate
+    model.set_precision("fp16")
+    got = model.diffusion.ddpm_sample(x_T.to(dev), model.predictor, steps, constrain=constrain, schedule=tmap,
+                                      noise=[n.to(dev) for n in noises]).cpu()
+    assert (rms(got - want) if constrain else rel_rms(got, want)) < WAVE_RMS
     model.set_precision("bf16")
     got = model.diffusion.ddpm_sample(x_T.to(dev), model.predictor, steps, constrain=constrain, schedule=tmap,
                                       noise=[n.to(dev) for n in noises]).cpu()
@@ -175,8 +183,12 @@ def test_vq_and_vqvae_vs_golden(golden, dev):
     codes = model.encode(wav.to(dev)).cpu()
     want = torch.from_numpy(z7["codes"])
     mism = codes != want
-    assert mism.sum().item() <= 2 and (torch.from_numpy(z7["gap"])[mism] < 1e-3).all()
+    assert mism.sum().item() == 0, f"{int(mism.sum())} codes differ; top-2 distance gaps there: {torch.from_numpy(z7['gap'])[mism].tolist()}"
     assert codes.dtype == torch.int64 and codes.shape == (2, 250)
+    # a 2-byte predictor precision must not touch the encoder: codes stay bit-exact
+    model.set_precision("fp16")
+    assert model.encoder.precision == "fp32" and torch.equal(model.encode(wav.to(dev)).cpu(), want)
+    model.set_precision("fp32")
     # conditional forward + decode
     cond = model.vq.embed(torch.from_numpy(z4["codes16"]).to(dev))
     eps = model.predictor(torch.from_numpy(z4["x"]).to(dev), torch.from_numpy(z4["ts"]).to(dev), cond=cond,
@@ -188,6 +200,57 @@ def test_vq_and_vqvae_vs_golden(golden, dev):
     dec = model.decode(torch.from_numpy(z8["codes16"]).to(dev), torch.from_numpy(z8["labels"]).to(dev), steps=5, constrain=True,
                        x_T=x_T.to(dev), noise=noises).cpu()
     assert rms(dec - torch.from_numpy(z8["x0"])) < WAVE_RMS
+    model.set_precision("fp16")
+    dec = model.decode(torch.from_numpy(z8["codes16"]).to(dev), torch.from_numpy(z8["labels"]).to(dev), steps=5, constrain=True,
+                       x_T=x_T.to(dev), noise=noises).cpu()
+    assert rms(dec - torch.from_numpy(z8["x0"])) < WAVE_RMS
+
+
+def test_time_embedding_vs_golden(golden, dev):
+    """F2: the conditioning vector (sinusoid with arguments up to 100 rad -> Linear -> GELU -> Linear + class embedding,
+    wavegrad.py:359-373, unet.py:133-135) read back from the handle after a forward."""
+    z = golden("f2_time_embed")
+    ts = torch.from_numpy(z["ts"])
+    for base in (32, 64):
+        model = det_model(DiffusionModel("unet", base, num_labels=6))
+        labels = torch.from_numpy(z[f"c{base}.labels"])
+        model.predictor(seeded((3, 1, 256), 1).to(dev), ts.to(dev), labels=labels.to(dev))
+        emb = model.predictor._handle.read_embedding(3)
+        want = torch.from_numpy(z[f"c{base}.emb"])
+        assert emb.shape == want.shape and (emb - want).abs().max().item() <= 2e-5, (base, (emb - want).abs().max().item())
+
+
+def test_ddpm_previous_cos_schedule_vs_golden(golden, dev):
+    """F5b: CosSchedule (schedule.py:34-41) through the same step kernels, away from the ill-conditioned t = 1."""
+    z = golden("f5b_ddpm_previous_cos")
+    d = Diffusion(make_schedule("cos"))
+    for i in range(5):
+        t, step = z[f"c{i}.t_step"]
+        x, eps, noise = (torch.from_numpy(z[f"c{i}.{k}"]).to(dev) for k in ("x", "eps", "noise"))
+        ts = torch.tensor([t, t], dtype=torch.float32, device=dev)
+        for mode, kw in (("plain", {}), ("sigma_large", dict(sigma_large=True)), ("constrain", dict(constrain=True))):
+            want = torch.from_numpy(z[f"c{i}.{mode}"])
+            got = d.ddpm_previous(x, ts, float(step), eps, noise=noise, **kw).cpu()
+            assert (got - want).abs().max().item() <= 4e-6 * max(1.0, want.abs().max().item()), (i, mode, (got - want).abs().max().item())
+
+
+def test_decode_uncond_guidance_vs_golden(golden, dev):
+    """F11: VQVAE.decode_uncond_guidance (vq_vae.py:147-220) against the reference's own output (both scales on)."""
+    z = golden("f11_uncond_guidance")
+    model = det_model(VQVAE(base_channels=32, pred_name="unet", num_labels=5))
+    with torch.no_grad():
+        model.vq.dictionary.copy_(seeded(model.vq.dictionary.shape, 77, 0.35))
+    steps = int(z["steps"])
+    x_T = seeded((2, 1, 2048), int(z["x_T_seed"]))
+    gen = torch.Generator().manual_seed(int(z["noise_seed"]))
+    noises = [torch.randn(x_T.shape, generator=gen).to(dev) for _ in range(steps)]
+    vq_scale, label_scale = (float(v) for v in z["scales"])
+    want = torch.from_numpy(z["x0"])
+    for prec in ("fp32", "fp16"):
+        model.set_precision(prec)
+        got = model.decode_uncond_guidance(torch.from_numpy(z["codes"]).to(dev), torch.from_numpy(z["labels"]).to(dev), steps=steps,
+                                           constrain=True, vq_scale=vq_scale, label_scale=label_scale, x_T=x_T.to(dev), noise=noises).cpu()
+        assert rms(got - want) < WAVE_RMS, (prec, rms(got - want))
 
 
 def test_unet64_full_size_forward_vs_oracle(dev):
@@ -196,9 +259,9 @@ def test_unet64_full_size_forward_vs_oracle(dev):
     x, ts = seeded((1, 1, 64000), 9), torch.tensor([0.4])
     sd = {"predictor." + k: v.detach() for k, v in model.predictor.state_dict().items()}
     want = ref_cpu.unet_predictor(sd, 64, x, ts)
-    assert rel_rms(model.predictor(x.to(dev), ts.to(dev)).cpu(), want) < FP32_REL
-    model.set_precision("bf16")
-    assert rel_rms(model.predictor(x.to(dev), ts.to(dev)).cpu(), want) < BF16_REL
+    for prec, tol in MODES:
+        model.set_precision(prec)
+        assert rel_rms(model.predictor(x.to(dev), ts.to(dev)).cpu(), want) < tol, prec
 
 
 def test_sharding_invariance_full_size(dev):
@@ -251,7 +314,7 @@ def test_decode_uncond_guidance_vs_oracle(dev):
     assert rms(got - want) < WAVE_RMS
 
 
-@pytest.mark.parametrize("prec,tol", [("fp32", FP32_REL), ("bf16", BF16_REL)])
+@pytest.mark.parametrize("prec,tol", MODES)
 def test_resblock_config_sweep_vs_oracle(dev, prec, tol):
     """Every kernel variant the schedule can pick (32/64/128-channel tiles, identity / 1x1 skip, avg / up resize,
     small and large dilation halo, ragged lengths, several clips) against the oracle on seeded inputs."""
@@ -299,3 +362,34 @@ def test_handle_lifecycle_and_small_shapes(dev):
     model.predictor.invalidate()
     torch.cuda.synchronize()
     assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20), "device memory of destroyed handles was not returned"
+
+
+def test_live_parameters_deepcopy_and_index_errors(dev):
+    """The reference reads live parameters on every call: an in-place weight update between two forwards must be seen
+    (the device snapshot is rebuilt); EMA-style deep copies work after a forward; out-of-range labels / codes raise like
+    nn.Embedding / F.embedding instead of being clamped."""
+    import copy
+    import pickle
+
+    model = det_model(DiffusionModel("unet", 32))
+    x, ts = seeded((2, 1, 512), 3).to(dev), torch.tensor([0.3, 0.8], device=dev)
+    a = model.predictor(x, ts)
+    with torch.no_grad():  # out = Conv(gelu(GN(h))): doubling weight and bias doubles the output exactly
+        model.predictor.out[1].weight.mul_(2.0)
+        model.predictor.out[1].bias.mul_(2.0)
+    b = model.predictor(x, ts)
+    assert torch.equal(b, 2.0 * a)
+    ema = copy.deepcopy(model)
+    assert torch.equal(ema.predictor(x, ts), b)
+    pickle.dumps(model.predictor)  # the ctypes handle is dropped from the pickled state
+    src = det_model(DiffusionModel("unet", 32))
+    assert model.load_from_pretrained(src) > 0
+    assert torch.equal(model.predictor(x, ts), a)
+    lab = det_model(DiffusionModel("unet", 32, num_labels=3))
+    with pytest.raises(IndexError):
+        lab.predictor(x, ts, labels=torch.tensor([0, 3], device=dev))
+    vq = VQVAE(base_channels=32, pred_name="unet").vq
+    with pytest.raises(IndexError):
+        vq.embed(torch.tensor([[0, 512]], device=dev))
+    with pytest.raises(IndexError):
+        vq.embed(torch.tensor([[-1, 5]], device=dev))

@@ -1,0 +1,117 @@
+"""Parity at the benchmarked sizes (BASELINE.json configs 3 and 4), on a real MI355X, through the C ABI.
+
+* unet64 at B = 64, T = 64000 -- the bench.py workload: arena offsets, the XCD-aware tile remap and the 32-bit buffer
+  offsets of a full batch -- checked through a size-independent property (a clip's result does not depend on the batch it
+  sits in: clips 0 / 31 / 63 of the 64-clip forward are BITWISE those of 1-clip forwards) plus the oracle on one clip;
+* a unet64 10-step constrained sample against the oracle (<= 1e-3 waveform RMS) in both gate modes;
+* BASELINE config 4 at base_channels = 64: UNetEncoder(64) (1024-channel output conv), VQ with Cd = 1024 (bit-exact,
+  margin-guaranteed and exact-tie sets), and the cond_proj 1024 -> 64 conditional forward."""
+import pytest
+import torch
+
+from oracle import ref_cpu
+from vq_voice_swap_amd import DiffusionModel, VQVAE
+from vq_voice_swap_amd.det_init import det_init_
+
+from util import rel_rms, rms, seeded
+
+pytestmark = pytest.mark.gpu
+torch.set_num_threads(8)  # same as every other test module: bit-exact CPU checks depend on the thread count
+
+GATE = {"fp32": 1e-4, "fp16": 4e-3}  # per-forward relative RMS on eps (measured 1.5e-5 / 1.3e-3)
+WAVE_RMS = 1e-3
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def det_model(m):
+    det_init_(m.state_dict().items())
+    m.eval()
+    return m
+
+
+@pytest.fixture(scope="module")
+def unet64():
+    model = det_model(DiffusionModel("unet", 64))
+    sd = {"predictor." + k: v.detach().clone() for k, v in model.predictor.state_dict().items()}
+    return model, sd
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+def test_unet64_bench_batch_forward(dev, unet64, prec):
+    model, sd = unet64
+    model.set_precision(prec)
+    B, T = 64, 64000
+    x = torch.randn(B, 1, T, generator=torch.Generator().manual_seed(123))
+    ts = torch.linspace(0.05, 0.95, B)
+    xd, tsd = x.to(dev), ts.to(dev)
+    full = model.predictor(xd, tsd)
+    assert bool(torch.isfinite(full).all())
+    for i in (0, 31, 63):
+        one = model.predictor(xd[i:i + 1].contiguous(), tsd[i:i + 1].contiguous())
+        assert torch.equal(full[i:i + 1], one), f"clip {i} of the 64-clip batch differs from its 1-clip forward ({prec})"
+    want = ref_cpu.unet_predictor(sd, 64, x[31:32], ts[31:32])
+    assert rel_rms(full[31:32].cpu(), want) < GATE[prec], prec
+    model.predictor.invalidate()  # give the 64-clip arena back
+
+
+def test_unet64_ten_step_sample_vs_oracle(dev, unet64):
+    model, sd = unet64
+    x_T = seeded((2, 1, 64000), 21)
+    gen = torch.Generator().manual_seed(22)
+    noises = [torch.randn(x_T.shape, generator=gen) for _ in range(10)]
+    want = ref_cpu.ddpm_sample("exp", x_T, lambda p, q: ref_cpu.unet_predictor(sd, 64, p, q), 10, noises, constrain=True)
+    for prec in ("fp32", "fp16"):
+        model.set_precision(prec)
+        got = model.diffusion.ddpm_sample(x_T.to(dev), model.predictor, 10, constrain=True, noise=[n.to(dev) for n in noises]).cpu()
+        assert rms(got - want) < WAVE_RMS, (prec, rms(got - want))
+    model.predictor.invalidate()
+
+
+def test_config4_base64_encoder_vq_and_cond_forward(dev):
+    model = det_model(VQVAE(base_channels=64, pred_name="unet", num_labels=7))
+    with torch.no_grad():
+        model.vq.dictionary.copy_(seeded(model.vq.dictionary.shape, 78, 0.35))
+    assert model.vq.dictionary.shape == (512, 1024)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    dic = sd["vq.dictionary"]
+    # UNetEncoder(64): z against the oracle, codes bit-exact
+    wav = seeded((2, 1, 64000), 31, 0.1).clamp(-1, 1)
+    z_want = ref_cpu.unet_encoder(sd, 64, wav)
+    z_got = model.encoder(wav.to(dev)).cpu()
+    assert z_got.shape == (2, 1024, 250) and rel_rms(z_got, z_want) < GATE["fp32"]
+    codes_want = ref_cpu.vq_encode(dic, z_want)
+    codes = model.encode(wav.to(dev)).cpu()
+    d = ref_cpu.vq_distances(dic, z_want.permute(0, 2, 1).reshape(-1, 1024))
+    top2 = torch.topk(d, 2, dim=-1, largest=False).values
+    gap = (top2[:, 1] - top2[:, 0]).reshape(2, -1)
+    mism = codes != codes_want
+    assert mism.sum().item() == 0, f"{int(mism.sum())} codes differ; top-2 gaps there: {gap[mism].tolist()}"
+    # VQ kernel alone at Cd = 1024: same z -> bit-exact; margin-guaranteed set; exact ties -> first index
+    assert torch.equal(model.vq.encode(z_want.to(dev)).cpu(), codes_want)
+    idx_m = torch.randint(0, 512, (2, 250), generator=torch.Generator().manual_seed(32))
+    zm = ref_cpu.vq_embed(dic, idx_m) + 1e-3 * seeded((2, 1024, 250), 33)
+    assert torch.equal(ref_cpu.vq_encode(dic, zm), idx_m) and torch.equal(model.vq.encode(zm.to(dev)).cpu(), idx_m)
+    assert torch.equal(model.vq.embed(idx_m.to(dev)).cpu(), ref_cpu.vq_embed(dic, idx_m))
+    with torch.no_grad():
+        d2 = dic.clone()
+        d2[400] = d2[23]
+        model.vq.dictionary.copy_(d2)
+    zt = ref_cpu.vq_embed(d2, torch.full((1, 6), 400))
+    assert model.vq.encode(zt.to(dev)).cpu().tolist() == [[23] * 6]
+    with torch.no_grad():
+        model.vq.dictionary.copy_(dic)
+    # conditional unet64 forward (cond_proj 1024 -> 64, labels) in both gate modes
+    T = 16384
+    x, ts = seeded((2, 1, T), 34), torch.tensor([0.7, 0.2])
+    cond = ref_cpu.vq_embed(dic, codes_want[:, : T // 256])
+    labels = torch.tensor([6, 0])
+    want = ref_cpu.unet_predictor(sd, 64, x, ts, cond=cond, labels=labels)
+    for prec in ("fp32", "fp16"):
+        model.set_precision(prec)
+        got = model.predictor(x.to(dev), ts.to(dev), cond=cond.to(dev), labels=labels.to(dev)).cpu()
+        assert rel_rms(got, want) < GATE[prec], (prec, rel_rms(got, want))

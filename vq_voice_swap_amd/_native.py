@@ -281,6 +281,24 @@ class Handle:
         return out
 
 
+_range_checked = {}
+
+
+def check_index_range(t, n: int, what: str) -> None:
+    """Raise IndexError, as nn.Embedding / F.embedding do (reference unet.py:45, vq.py:108), when an index tensor holds
+    values outside [0, n).  The kernels clamp instead of faulting, which would turn a caller bug into plausible audio.
+    The check costs one device->host sync, so a tensor that was already checked (same storage, same version -- the
+    labels of a sampling loop) is not checked again."""
+    key = (what, t.data_ptr(), t._version, t.numel(), n)
+    if _range_checked.get(what) == key:
+        return
+    if t.numel():
+        lo, hi = int(t.min().item()), int(t.max().item())
+        if lo < 0 or hi >= n:
+            raise IndexError(f"{what}: index out of range (values span [{lo}, {hi}], valid range is [0, {n - 1}])")
+    _range_checked[what] = key
+
+
 def require_cuda(*tensors) -> None:
     for t in tensors:
         if t is not None and not t.is_cuda:

@@ -11,53 +11,20 @@ of log p(y | x_t) with respect to x_t -- which the reference obtains with `torch
 (`sample_diffusion.py:34-42`) -- is an explicit backward schedule (transposed convolutions on the MFMA kernel,
 GroupNorm / GELU / avg-pool / attention-pool backward kernels).  There is no CPU path: CPU tensors raise.
 
-`forward_torch` evaluates the same module with stock differentiable PyTorch ops.  It exists for the CPU tests
-that pin the parameter layout against the reference's golden vectors and for training-side code; nothing on
-the sampling path calls it.
+The classes below are parameter containers (reference state-dict names and shapes); there is no stock-torch
+evaluation of them in this package -- the CPU restatement lives in oracle/ref_cpu.py (test infrastructure).
 """
 
 from __future__ import annotations
 
-import math
 from typing import Any, Dict
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .base import Savable
 from . import _native
 from .unet import CHANNEL_MULT, ResBlock, _NativeModule, _groups, _scaled, _seq
-
-
-def _gn(x: torch.Tensor, gn: nn.GroupNorm) -> torch.Tensor:
-    return F.group_norm(x, gn.num_groups, gn.weight, gn.bias, gn.eps)
-
-
-def resblock_autograd(block: ResBlock, x: torch.Tensor, emb: torch.Tensor) -> torch.Tensor:
-    """Differentiable evaluation of one residual block from its parameter container."""
-    down = block.scale_factor < 1.0
-    up = block.scale_factor > 1.0
-
-    def resize(t):
-        if down:
-            return F.avg_pool1d(t, 2)
-        if up:
-            return F.interpolate(t, scale_factor=2.0)
-        return t
-
-    h = F.gelu(_gn(x, block.pre_cond[0][0]))
-    h = block.pre_cond[2](resize(h))
-    h = _gn(h, block.pre_cond[3])
-    if block.emb_channels:
-        ab = block.cond_layers[1](F.gelu(emb))[..., None]
-        a, b = ab[:, : block.out_channels], ab[:, block.out_channels:]
-        h = h * (a + 1) + b
-    h = block.post_cond[len(block.post_cond) - 1](F.gelu(h))
-    s = resize(x)
-    if isinstance(block.skip[1], nn.Conv1d):
-        s = block.skip[1](s)
-    return s + h
 
 
 class AttentionPool1d(nn.Module):
@@ -67,19 +34,6 @@ class AttentionPool1d(nn.Module):
         self.qkv_proj = nn.Conv1d(channels, 3 * channels, 1)
         self.c_proj = nn.Conv1d(channels, out_channels or channels, 1)
         self.num_heads = channels // head_channels
-
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        n, c, t = x.shape
-        x = torch.cat([x.new_zeros(n, c, 1), x], dim=-1)          # query token 0 is all zeros (classifier.py:154)
-        q, k, v = self.qkv_proj(x).chunk(3, dim=1)
-        ch = c // self.num_heads
-        s = ch ** -0.25                                              # both q and k are scaled (classifier.py:181-186)
-        q = (q * s).reshape(n * self.num_heads, ch, t + 1)
-        k = (k * s).reshape(n * self.num_heads, ch, t + 1)
-        v = v.reshape(n * self.num_heads, ch, t + 1)
-        w = torch.softmax(torch.einsum("bct,bcs->bts", q, k), dim=-1)
-        a = torch.einsum("bts,bcs->bct", w, v).reshape(n, c, t + 1)
-        return self.c_proj(a)[..., 0]
 
 
 class ClassifierStem(nn.Module):
@@ -102,22 +56,6 @@ class ClassifierStem(nn.Module):
         self.blocks = nn.ModuleList(blocks)
         self.out = _seq(_seq(nn.GroupNorm(_groups(cur), cur), None),
                         AttentionPool1d(cur, head_channels=min(cur, 64), out_channels=self.out_channels))
-
-    def conditional_embedding(self, ts: torch.Tensor) -> torch.Tensor:
-        E = self.embed_dim
-        half = E // 2
-        freqs = (torch.exp(-math.log(100.0 / 0.1) * torch.arange(0, half, dtype=torch.float32) / (half - 1)) * 100.0).to(ts)
-        args = ts[:, None] * freqs[None]
-        e = self.time_embed.proj(torch.cat([torch.cos(args), torch.sin(args)], dim=-1))
-        return self.time_embed_extra[1](F.gelu(e))
-
-    def forward(self, x: torch.Tensor, ts: torch.Tensor, use_checkpoint: bool = False) -> torch.Tensor:
-        emb = self.conditional_embedding(ts)
-        h = self.in_conv(x)
-        for block in self.blocks:
-            h = resblock_autograd(block, h, emb)
-        h = F.gelu(_gn(h, self.out[0][0]))
-        return self.out[1](h)
 
 
 class Classifier(_NativeModule, Savable):
@@ -191,7 +129,3 @@ class Classifier(_NativeModule, Savable):
             return self.log_prob_grad(x, ts, labels.to(x.device), scale)
 
         return cond_fn
-
-    def forward_torch(self, x: torch.Tensor, ts: torch.Tensor) -> torch.Tensor:
-        """The same function with stock differentiable PyTorch ops (tests / training-side code only)."""
-        return self.out[1](F.gelu(self.stem(x, ts)))

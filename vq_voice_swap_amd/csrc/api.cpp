@@ -1,5 +1,6 @@
 // extern "C" surface of libvqvs_hip.so (declared and documented in include/vqvs.h).
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 
@@ -10,30 +11,31 @@ namespace vqvs {
 static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
 
-// scratch shared by the handle-less entry points (DDPM step partial sums, VQ code norms)
-struct GlobalScratch {
+// scratch of the handle-less entry points (DDPM step partial sums, VQ code norms, discarded logits): one buffer per
+// device, owned by that device.  It only ever grows; growing synchronises the OWNING device (which is the current one:
+// the map is keyed by hipGetDevice) before the old buffer is freed, so no queued kernel can still be using it.
+struct DeviceScratch {
   void* p = nullptr;
   size_t bytes = 0;
-  int device = -1;
 };
-static GlobalScratch g_scratch;
+static std::map<int, DeviceScratch> g_scratch;
 static std::mutex g_scratch_mu;
 static int scratch_get(size_t bytes, void** out) {
   std::lock_guard<std::mutex> lk(g_scratch_mu);
   int dev = 0;
   VQVS_HIP(hipGetDevice(&dev));
-  if (g_scratch.p && (g_scratch.device != dev || g_scratch.bytes < bytes)) {
+  DeviceScratch& sc = g_scratch[dev];
+  if (sc.p && sc.bytes < bytes) {
     VQVS_HIP(hipDeviceSynchronize());
-    VQVS_HIP(hipFree(g_scratch.p));
-    g_scratch = GlobalScratch{};
+    VQVS_HIP(hipFree(sc.p));
+    sc = DeviceScratch{};
   }
-  if (!g_scratch.p) {
-    size_t n = bytes < (size_t)(1 << 20) ? (size_t)(1 << 20) : bytes;
-    VQVS_HIP(hipMalloc(&g_scratch.p, n));
-    g_scratch.bytes = n;
-    g_scratch.device = dev;
+  if (!sc.p) {
+    size_t n = bytes < (size_t)(4 << 20) ? (size_t)(4 << 20) : bytes;
+    VQVS_HIP(hipMalloc(&sc.p, n));
+    sc.bytes = n;
   }
-  *out = g_scratch.p;
+  *out = sc.p;
   return 0;
 }
 }  // namespace vqvs

@@ -791,8 +791,8 @@ static int check_cfg(const vqvs_cfg& c) {
     if (c.rb_emb_channels % 64) VQVS_FAIL(VQVS_ERR_ARG, "resblock emb channels must be a multiple of 64");
     return 0;
   }
-  if (c.base_channels < 32 || c.base_channels % 32 || c.base_channels > 128) VQVS_FAIL(VQVS_ERR_ARG, "base_channels must be 32, 64, 96 or 128 (got %d)", c.base_channels);
-  if (c.base_channels & (c.base_channels - 1)) VQVS_FAIL(VQVS_ERR_ARG, "base_channels must be a power of two (got %d)", c.base_channels);
+  // the reference's configurations are 32 and 64; wider bases would need GroupNorm over > 1024 concatenated channels
+  if (c.base_channels != 32 && c.base_channels != 64) VQVS_FAIL(VQVS_ERR_ARG, "base_channels must be 32 or 64 (got %d)", c.base_channels);
   if (c.in_channels != 1) VQVS_FAIL(VQVS_ERR_ARG, "in_channels must be 1 (got %d)", c.in_channels);
   if (c.max_T % 256) VQVS_FAIL(VQVS_ERR_ARG, "max_T must be a multiple of 256 (got %d)", c.max_T);
   // the kernels address rows of one clip with 32-bit byte offsets (buffer loads): the widest per-clip tensor must stay below 2 GiB

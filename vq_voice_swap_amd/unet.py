@@ -266,6 +266,9 @@ class UNetPredictor(_NativeModule):
                 raise ValueError(f"expected cond of shape {(B, self.cond_channels, T // 256)}, got {tuple(cond.shape)}")
         if labels is not None:
             labels = labels.detach().to(device=x.device, dtype=torch.int64).contiguous()
+            if labels.shape != (B,):
+                raise ValueError(f"expected labels of shape [{B}], got {tuple(labels.shape)}")
+            _native.check_index_range(labels, self.num_labels, "class labels")
         h = self.handle(x.device, B, T)
         out = torch.empty(B, self.out_channels, T, device=x.device, dtype=torch.float32)
         with torch.cuda.device(x.device):

@@ -28,6 +28,7 @@ class VQ(nn.Module):
         _native.require_cuda(idxs)
         n = idxs.shape[0]
         flat = idxs.detach().reshape(n, -1).to(torch.int64).contiguous()
+        _native.check_index_range(flat, self.num_codes, "VQ codes")
         d = self.dictionary.detach().to(device=flat.device, dtype=torch.float32).contiguous()
         out = torch.empty(n, self.num_channels, flat.shape[1], device=flat.device, dtype=torch.float32)
         with torch.cuda.device(flat.device):
