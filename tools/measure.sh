@@ -1,0 +1,25 @@
+# Measurement pass on the GPU box for ONE precision mode (default fp16, the benchmarked mode):
+#   gpurun -- 'bash tools/measure.sh [fp16|bf16|fp32] [tag]'
+# Writes under gpurun_out/<tag>/: the bench line, the per-op table (live hipEvents), the rocprofv3 --kernel-trace --stats
+# summary of the same bench command (labelled by mode: the bench runs ONLY that mode, --no-other-modes), and the per-launch
+# HBM traffic from two separate --pmc passes (FETCH_SIZE, WRITE_SIZE; MI355X_MICROARCH.md: never combined with other traces).
+PREC=${1:-fp16}
+TAG=${2:-meas_$PREC}
+cd $GRAFT_REPO_ROOT
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+timeout 900 python bench.py --precision $PREC > $OUT/bench_$PREC.json 2> $OUT/bench_$PREC.err; tail -c 400 $OUT/bench_$PREC.json
+timeout 300 python tools/profile_ops.py --precision $PREC > $OUT/ops_unet64_$PREC.txt 2>&1
+cd /tmp && rm -rf /tmp/prof_stats
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o stats -- python $GRAFT_REPO_ROOT/bench.py --precision $PREC --steps 2 --warmup 0 --no-cpu-baseline --no-other-modes > $OUT/bench_under_rocprof_$PREC.json 2> $OUT/bench_under_rocprof_$PREC.err
+cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_$PREC.csv
+head -5 $OUT/kernel_stats_$PREC.csv
+if [ "$3" != "nopmc" ]; then
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmc_$c
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o pmc -- python $GRAFT_REPO_ROOT/tools/profile_ops.py --precision $PREC --reps 1 > /tmp/pmc_$c.log 2>&1
+done
+NKERNELS=$(python -c "print(open('$OUT/ops_unet64_$PREC.txt').read().split(' kernels')[0].split()[-1])") python $GRAFT_REPO_ROOT/tools/pmc_per_op.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE > $OUT/pmc_traffic_per_op_unet64_$PREC.csv
+head -3 $OUT/pmc_traffic_per_op_unet64_$PREC.csv
+fi
