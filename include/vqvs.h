@@ -45,6 +45,11 @@ extern "C" {
 #define VQVS_KIND_ENCPRED 4    /* EncoderPredictor (reference models/encoder_predictor.py:14-75): base_channels, out_channels =
                                   bottleneck_dim, reserved[1] = downsample_rate, reserved[2] = num_latents */
 
+#define VQVS_KIND_MFCC_ENCODER 5 /* ConvMFCCEncoder (reference models/conv_encoder.py:14-133): base_channels, out_channels,
+                                  reserved[1] = version (1: n_fft 320, 40 mels, log; 2: n_fft 400, 80 mels, dB, normalized),
+                                  reserved[2] = input_ulaw.  fp32 precision only.  Its parameter table starts with the three
+                                  buffers of torchaudio.transforms.MFCC that a reference checkpoint carries (mfcc.dct_mat, ...) */
+
 /* activation storage / arithmetic */
 #define VQVS_PREC_F32 0  /* fp32 activations; convs as 3-term bf16-split MFMA, fp32 accumulate (~2^-17 rel.) */
 #define VQVS_PREC_BF16 1 /* bf16 activations; bf16 MFMA, fp32 accumulate */
@@ -91,7 +96,9 @@ int64_t vqvs_model_device_bytes(const vqvs_model* m);
 /* ---- UNet forward -----------------------------------------------------------
  * eps = UNetPredictor.forward(x, ts, cond=, labels=)   reference unet.py:118-163
  *   d_x     [B,1,T] f32      d_ts [B] f32
- *   d_cond  [B,cond_channels,T/256] f32 or NULL (must match cfg, unet.py:126-131)
+ *   d_cond  [B,cond_channels,T1] f32 or NULL (must match cfg, unet.py:126-131); T1 = T/256 (cfg.reserved[3] = 0: cond from a
+ *           UNet encoder) or (T/160 + 1 - 2)/2 + 1 = T/320 (reserved[3] = 1: cond from the MFCC encoder); it is added to the
+ *           in_conv output through nearest-neighbour up-sampling to T, as F.interpolate does (unet.py:139)
  *   d_labels[B] int64 or NULL (must match cfg)
  *   d_out   [B,out_channels,T] f32 */
 int vqvs_unet_forward(vqvs_model* m, const float* d_x, const float* d_ts, const float* d_cond,
@@ -100,6 +107,13 @@ int vqvs_unet_forward(vqvs_model* m, const float* d_x, const float* d_ts, const 
 /* z = UNetEncoder.forward(x)   reference unet.py:229-241
  *   d_x [B,1,T] f32 -> d_z [B,out_channels,T/256] f32 (NCT) */
 int vqvs_encoder_forward(vqvs_model* m, const float* d_x, float* d_z, int B, int T, void* stream);
+
+/* z = ConvMFCCEncoder.forward(x)   reference models/conv_encoder.py:90-110 (VQVS_KIND_MFCC_ENCODER handles):
+ * mu-law expansion, MFCC (13 coefficients at 100 frames/s) with first and second order deltas, convolution stack.
+ *   d_x [B,1,T] f32 -> d_z [B,out_channels,(T/160 + 1 - 2)/2 + 1] f32 (NCT): 200 positions for 4 s at 16 kHz.
+ * The dB variant (version 2) floors the log-mel spectrogram at (maximum over the WHOLE batch) - 80, as
+ * torchaudio.functional.amplitude_to_DB does for a 3-D input: its results depend on the batch composition. */
+int vqvs_mfcc_encoder_forward(vqvs_model* m, const float* d_x, float* d_z, int B, int T, void* stream);
 
 /* y = ResBlock.forward(x, emb)   reference unet.py:307-316 (VQVS_KIND_RESBLOCK handles)
  *   d_x [B,rb_cin,L] f32, d_emb [B,rb_emb_channels] f32 or NULL -> d_y [B,rb_cout,L'] f32 */
@@ -162,6 +176,8 @@ int vqvs_vq_embed(const int64_t* d_idx, const float* d_dict, float* d_out, int B
 /* ---- test / profiling hooks ------------------------------------------------------ */
 int vqvs_debug_tap_count(const vqvs_model* m);
 int vqvs_debug_tap_info(const vqvs_model* m, int i, char* name_out, int name_cap, int* channels, int* length_shift);
+/* rows per clip of tap i at clip length T (UNet taps: T >> length_shift; MFCC encoder taps: frame counts) */
+int vqvs_debug_tap_rows(const vqvs_model* m, int i, int T);
 /* copies tap i of the LAST forward to host as float32 NCT [B][C][L]; synchronises the device */
 int vqvs_debug_read_tap(vqvs_model* m, int i, int B, int T, float* h_out);
 /* copies the conditioning vector of the LAST forward -- time_embed_extra(time_embed(ts)) [+ class_embed(labels)], reference

@@ -438,3 +438,117 @@ def vqvae_decode_uncond_guidance(
         return b + vq_scale * (b - outs[n:2 * n]) + label_scale * (b - outs[2 * n:])
 
     return ddpm_sample(schedule, x_T, pred_fn, steps, noises, constrain=constrain)
+
+
+# --------------------------------------------------------------------------
+# ConvMFCCEncoder (models/conv_encoder.py:14-133).  PARITY UNPINNED for the MFCC front end: the reference builds it from
+# `torchaudio.transforms.MFCC` (conv_encoder.py:42-58), and torchaudio is not installed in the build container (SURVEY.md
+# 8c), so the front end below restates torchaudio's published algorithm -- transforms.MFCC / MelSpectrogram / Spectrogram /
+# MelScale / AmplitudeToDB and functional.create_dct / melscale_fbanks / amplitude_to_DB (torchaudio 0.8 ... 2.x, same
+# arithmetic throughout) -- and cannot be checked against the reference's own output here.  The three constant tensors of
+# the transform (Hann window, mel filter bank, DCT matrix) are persistent buffers of the reference module, so a reference
+# checkpoint carries them ("encoder.mfcc.*"); both this oracle and the HIP path read them from the state dict.  The
+# convolution stack after the front end, `deltas` and `invert_ulaw` ARE the reference's own code and are restated 1:1.
+# --------------------------------------------------------------------------
+
+
+def mfcc_config(version: int = 1, input_rate: int = 16000, mfcc_rate: int = 100) -> dict:
+    """conv_encoder.py:44-58."""
+    hop = input_rate // mfcc_rate
+    n_fft = round(400 * input_rate / 16000) if version == 2 else hop * 2
+    return dict(n_fft=n_fft, hop=hop, n_mels=40 if version == 1 else 80, n_mfcc=13, log_mels=version == 1,
+                normalized=version == 2, sample_rate=input_rate)
+
+
+def mfcc_buffers(cfg: dict) -> State:
+    """The transform's constant tensors under the reference's buffer names.
+    torchaudio.functional.melscale_fbanks(n_freqs, 0, sr/2, n_mels, sr, norm=None, mel_scale="htk") and
+    create_dct(n_mfcc, n_mels, norm="ortho"); window = torch.hann_window(n_fft) (periodic)."""
+    n_fft, n_mels, n_mfcc, sr = cfg["n_fft"], cfg["n_mels"], cfg["n_mfcc"], cfg["sample_rate"]
+    n_freqs = n_fft // 2 + 1
+    all_freqs = torch.linspace(0, sr // 2, n_freqs)
+    m_min = 2595.0 * math.log10(1.0 + 0.0 / 700.0)
+    m_max = 2595.0 * math.log10(1.0 + float(sr // 2) / 700.0)
+    m_pts = torch.linspace(m_min, m_max, n_mels + 2)
+    f_pts = 700.0 * (10 ** (m_pts / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    down = (-1.0 * slopes[:, :-2]) / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    fb = torch.max(torch.zeros(1), torch.min(down, up))
+    n = torch.arange(float(n_mels))
+    k = torch.arange(float(n_mfcc)).unsqueeze(1)
+    dct = torch.cos(math.pi / float(n_mels) * (n + 0.5) * k)
+    dct[0] *= 1.0 / math.sqrt(2.0)
+    dct *= math.sqrt(2.0 / float(n_mels))
+    return {
+        "mfcc.MelSpectrogram.spectrogram.window": torch.hann_window(n_fft),
+        "mfcc.MelSpectrogram.mel_scale.fb": fb,
+        "mfcc.dct_mat": dct.t().contiguous(),
+    }
+
+
+def invert_ulaw(x: Tensor, mu: float = 255.0) -> Tensor:
+    """conv_encoder.py:132-133."""
+    return x.sign() * (1 / mu) * ((1 + mu) ** x.abs() - 1)
+
+
+def deltas(seq: Tensor) -> Tensor:
+    """conv_encoder.py:123-129."""
+    right_shifted = torch.cat([seq[..., :1], seq[..., :-1]], dim=-1)
+    left_shifted = torch.cat([seq[..., 1:], seq[..., -1:]], dim=-1)
+    d1 = right_shifted - seq
+    d2 = seq - left_shifted
+    return (d1 + d2) / 2
+
+
+def mfcc_transform(wave: Tensor, sd: State, cfg: dict, prefix: str = "") -> Tensor:
+    """torchaudio.transforms.MFCC.forward on a [N, T] waveform -> [N, n_mfcc, T // hop + 1]."""
+    window = sd[prefix + "mfcc.MelSpectrogram.spectrogram.window"]
+    fb = sd[prefix + "mfcc.MelSpectrogram.mel_scale.fb"]
+    dct = sd[prefix + "mfcc.dct_mat"]
+    n_fft, hop = cfg["n_fft"], cfg["hop"]
+    # functional.spectrogram: torch.stft(center=True, pad_mode="reflect", onesided, normalized=False), then the "window"
+    # normalisation (spec /= sqrt(sum window^2)) when `normalized`, then |.|^2 (power = 2)
+    spec = torch.stft(wave, n_fft, hop_length=hop, win_length=n_fft, window=window, center=True, pad_mode="reflect",
+                      normalized=False, onesided=True, return_complex=True)
+    if cfg["normalized"]:
+        spec = spec / window.pow(2.0).sum().sqrt()
+    power = spec.abs().pow(2.0)                                            # [N, n_freqs, frames]
+    mel = torch.matmul(power.transpose(-1, -2), fb).transpose(-1, -2)      # MelScale.forward
+    if cfg["log_mels"]:
+        mel = torch.log(mel + 1e-6)
+    else:
+        # AmplitudeToDB("power", top_db=80): 10 log10(clamp(x, 1e-10)); for a 3-D input the batch axis is taken for the
+        # channel axis (functional.amplitude_to_DB reshapes to [-1, shape[-3], freq, time]) -> ONE maximum over the whole batch
+        mel = 10.0 * torch.log10(torch.clamp(mel, min=1e-10))
+        mel = torch.max(mel, mel.max() - 80.0)
+    return torch.matmul(mel.transpose(-1, -2), dct).transpose(-1, -2)
+
+
+def conv_mfcc_encoder(sd: State, x: Tensor, version: int = 1, input_ulaw: bool = True, prefix: str = "encoder.",
+                      probe: Optional[Callable[[str, Tensor], None]] = None) -> Tensor:
+    """ConvMFCCEncoder.forward (conv_encoder.py:90-110): [N,1,T] -> [N, out_channels, (T // hop + 1 - 2) // 2 + 1]."""
+    p = prefix
+    cfg = mfcc_config(version)
+    assert x.shape[1] == 1, "input must only have one channel"
+    if input_ulaw:
+        x = invert_ulaw(x)
+    h = mfcc_transform(x[:, 0, :], sd, cfg, p)
+    deriv = deltas(h)
+    accel = deltas(deriv)
+    h = torch.cat([h, deriv, accel], dim=1)
+    if probe:
+        probe("features", h)
+
+    def res_conv(h, i, pad):
+        return h + F.gelu(F.conv1d(h, sd[f"{p}blocks.{i}.conv.weight"], sd[f"{p}blocks.{i}.conv.bias"], padding=pad))
+
+    h = F.gelu(F.conv1d(h, sd[p + "blocks.0.0.weight"], sd[p + "blocks.0.0.bias"], padding=1))
+    h = res_conv(h, 1, 1)
+    h = F.gelu(F.conv1d(h, sd[p + "blocks.2.0.weight"], sd[p + "blocks.2.0.bias"], stride=2, padding=1))
+    for i in (3, 4):
+        h = res_conv(h, i, 1)
+    for i in (5, 6, 7, 8):
+        h = res_conv(h, i, 0)
+    return F.conv1d(h, sd[p + "blocks.9.weight"], sd[p + "blocks.9.bias"])

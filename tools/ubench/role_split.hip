@@ -13,7 +13,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // NM MFMAs per consumer wave and iteration, NV packed-fp32 FMAs per producer wave and iteration (+ NV/8 cvt),
 // LDS: consumers read NM fragments (ds_read_b128), producers write NV/16 x 16 bytes.  ROLE: 0 both, 1 consumers only
 // (producers idle at the barrier), 2 producers only, 3 every wave does BOTH (half the MFMAs and half the VALU each).
-template <int NM, int NV, int ROLE>
+template <int NM, int NV, int ROLE, int KIND>
 __global__ __launch_bounds__(512) void k(float* out, int iters, float seed) {
   __shared__ __attribute__((aligned(16))) char lds[64 * 1024];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -34,9 +34,29 @@ __global__ __launch_bounds__(512) void k(float* out, int iters, float seed) {
       acc[m & 7] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, b, acc[m & 7], 0, 0, 0);
     }
   };
+  // KIND 0: n packed-fp32 FMAs (v_pk_fma_f32, 128 flops per lane pair);  KIND 1: the same arithmetic as 2n scalar v_fma_f32;
+  // KIND 2: 2n scalar FMAs with literal constants (v_fmaak_f32 / v_fmac_f32: VOP2 encodings)
   auto valu_part = [&](int n) {
+    if constexpr (KIND == 0) {
 #pragma unroll
-    for (int q = 0; q < n; ++q) v[q & 7] = __builtin_elementwise_fma(v[q & 7], c, d);
+      for (int q = 0; q < n; ++q) v[q & 7] = __builtin_elementwise_fma(v[q & 7], c, d);
+    } else if constexpr (KIND == 1) {
+#pragma unroll
+      for (int q = 0; q < n; ++q) {
+        float x = v[q & 7][0], y = v[q & 7][1];
+        asm volatile("v_fma_f32 %0, %0, %2, %3\n\tv_fma_f32 %1, %1, %2, %3" : "+v"(x), "+v"(y) : "v"(c[0]), "v"(d[0]));
+        v[q & 7][0] = x;
+        v[q & 7][1] = y;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < n; ++q) {
+        float x = v[q & 7][0], y = v[q & 7][1];
+        asm volatile("v_fmaak_f32 %0, %0, %2, 0x3e800000\n\tv_fmaak_f32 %1, %1, %2, 0x3e800000" : "+v"(x), "+v"(y) : "v"(c[0]));
+        v[q & 7][0] = x;
+        v[q & 7][1] = y;
+      }
+    }
 #pragma unroll
     for (int q = 0; q < n / 16; ++q) {
       f16x8 h;
@@ -61,7 +81,7 @@ __global__ __launch_bounds__(512) void k(float* out, int iters, float seed) {
   out[blockIdx.x * 512 + tid] = s;
 }
 
-template <int NM, int NV, int ROLE>
+template <int NM, int NV, int ROLE, int KIND>
 float run() {
   float* d;
   (void)hipMalloc(&d, 256 * 512 * 4);
@@ -69,9 +89,9 @@ float run() {
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
-  hipLaunchKernelGGL((k<NM, NV, ROLE>), dim3(256), dim3(512), 0, 0, d, 10, 1.0f);
+  hipLaunchKernelGGL((k<NM, NV, ROLE, KIND>), dim3(256), dim3(512), 0, 0, d, 10, 1.0f);
   (void)hipEventRecord(e0);
-  hipLaunchKernelGGL((k<NM, NV, ROLE>), dim3(256), dim3(512), 0, 0, d, iters, 1.0f);
+  hipLaunchKernelGGL((k<NM, NV, ROLE, KIND>), dim3(256), dim3(512), 0, 0, d, iters, 1.0f);
   (void)hipEventRecord(e1);
   (void)hipEventSynchronize(e1);
   float ms;
@@ -80,20 +100,24 @@ float run() {
   return ms * 1e6f / iters;  // ns per iteration
 }
 
-template <int NM, int NV>
+template <int NM, int NV, int KIND>
 void row() {
-  const float both = run<NM, NV, 0>(), cons = run<NM, NV, 1>(), prod = run<NM, NV, 2>(), mixed = run<NM, NV, 3>();
-  printf("MFMA/iter=%3d  pkFMA/iter=%3d : consumers alone %7.1f ns  producers alone %7.1f ns  split roles %7.1f ns  (max %7.1f, sum %7.1f)"
-         "  every wave both %7.1f ns\n", NM, NV, cons, prod, both, cons > prod ? cons : prod, cons + prod, mixed);
+  const float both = run<NM, NV, 0, KIND>(), cons = run<NM, NV, 1, KIND>(), prod = run<NM, NV, 2, KIND>(), mixed = run<NM, NV, 3, KIND>();
+  printf("%s MFMA/iter=%3d  pkFMA-equivalents/iter=%3d : consumers alone %7.1f ns  producers alone %7.1f ns  split roles %7.1f ns  (max %7.1f, sum %7.1f)"
+         "  every wave both %7.1f ns\n", KIND == 0 ? "v_pk_fma_f32" : KIND == 1 ? "v_fma_f32   " : "v_fmaak_f32 ", NM, NV, cons, prod, both, cons > prod ? cons : prod, cons + prod, mixed);
 }
 
 int main() {
-  row<24, 64>();
-  row<24, 128>();
-  row<24, 256>();
-  row<48, 64>();
-  row<48, 128>();
-  row<48, 256>();
-  row<48, 384>();
+  row<24, 64, 0>();
+  row<24, 128, 0>();
+  row<48, 128, 0>();
+  row<48, 256, 0>();
+  row<24, 64, 1>();
+  row<24, 128, 1>();
+  row<48, 128, 1>();
+  row<48, 256, 1>();
+  row<24, 128, 2>();
+  row<48, 128, 2>();
+  row<48, 256, 2>();
   return 0;
 }

@@ -5,6 +5,7 @@ DiffusionModel / VQVAE API of unixpickle/vq-voice-swap.  See DESIGN.md.
 
 from .base import Savable, atomic_save
 from .classifier import Classifier
+from .conv_encoder import ConvMFCCEncoder
 from .diffusion import CosSchedule, Diffusion, ExpSchedule, Schedule, make_schedule, randn_clips
 from .diffusion_model import DiffusionModel
 from .encoder_predictor import EncoderPredictor
@@ -14,5 +15,5 @@ from .vq_vae import VQVAE
 
 __all__ = [
     "Savable", "atomic_save", "CosSchedule", "Diffusion", "ExpSchedule", "Schedule", "make_schedule", "randn_clips",
-    "DiffusionModel", "Classifier", "EncoderPredictor", "ResBlockModule", "UNetEncoder", "UNetPredictor", "VQ", "VQVAE",
+    "DiffusionModel", "Classifier", "ConvMFCCEncoder", "EncoderPredictor", "ResBlockModule", "UNetEncoder", "UNetPredictor", "VQ", "VQVAE",
 ]

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VQVS_LIB_PATH") or os.path.join(_HERE, "libvqvs_hip.so")  # override: instrumented builds (tools/)
 CSRC = os.path.join(_HERE, "csrc")
 
-KIND_PREDICTOR, KIND_ENCODER, KIND_RESBLOCK, KIND_CLASSIFIER, KIND_ENCPRED = 0, 1, 2, 3, 4
+KIND_PREDICTOR, KIND_ENCODER, KIND_RESBLOCK, KIND_CLASSIFIER, KIND_ENCPRED, KIND_MFCC_ENCODER = 0, 1, 2, 3, 4, 5
 PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
 DDPM_SIGMA_LARGE, DDPM_CONSTRAIN = 1, 2
 PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "float32": PREC_F32, "bf16": PREC_BF16, "bfloat16": PREC_BF16,
@@ -47,10 +47,10 @@ class Cfg(C.Structure):
 
 EXPORTS = [
     "vqvs_param_count", "vqvs_param_info", "vqvs_model_create", "vqvs_model_destroy", "vqvs_model_device_bytes",
-    "vqvs_unet_forward", "vqvs_encoder_forward", "vqvs_resblock_forward", "vqvs_classifier_forward",
+    "vqvs_unet_forward", "vqvs_encoder_forward", "vqvs_mfcc_encoder_forward", "vqvs_resblock_forward", "vqvs_classifier_forward",
     "vqvs_classifier_guidance", "vqvs_encpred_forward", "vqvs_encpred_guidance", "vqvs_ddpm_step", "vqvs_ddpm_mean",
     "vqvs_ddpm_guided_eps", "vqvs_randn", "vqvs_vq_argmin", "vqvs_vq_embed", "vqvs_debug_tap_count",
-    "vqvs_debug_tap_info", "vqvs_debug_read_tap", "vqvs_debug_read_embedding", "vqvs_forward_kernel_count", "vqvs_forward_model_bytes",
+    "vqvs_debug_tap_info", "vqvs_debug_tap_rows", "vqvs_debug_read_tap", "vqvs_debug_read_embedding", "vqvs_forward_kernel_count", "vqvs_forward_model_bytes",
     "vqvs_forward_flops", "vqvs_set_profiling", "vqvs_op_info", "vqvs_op_desc", "vqvs_profile_read", "vqvs_last_error", "vqvs_version",
 ]
 
@@ -96,6 +96,7 @@ def lib():
     L.vqvs_model_device_bytes.restype = i64
     L.vqvs_unet_forward.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp]
     L.vqvs_encoder_forward.argtypes = [vp, vp, vp, i32, i32, vp]
+    L.vqvs_mfcc_encoder_forward.argtypes = [vp, vp, vp, i32, i32, vp]
     L.vqvs_resblock_forward.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     L.vqvs_classifier_forward.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     L.vqvs_classifier_guidance.argtypes = [vp, vp, vp, vp, f32, vp, vp, i32, i32, vp]
@@ -109,6 +110,7 @@ def lib():
     L.vqvs_vq_embed.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
     L.vqvs_debug_tap_count.argtypes = [vp]
     L.vqvs_debug_tap_info.argtypes = [vp, i32, C.c_char_p, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.vqvs_debug_tap_rows.argtypes = [vp, i32, i32]
     L.vqvs_debug_read_tap.argtypes = [vp, i32, i32, i32, vp]
     L.vqvs_debug_read_embedding.argtypes = [vp, i32, vp]
     L.vqvs_forward_kernel_count.argtypes = [vp]
@@ -274,8 +276,10 @@ class Handle:
     def read_tap(self, i: int, B: int, T: int):
         import torch
 
-        _, ch, ls = self.taps()[i]
-        Lx = (T >> ls) if ls >= 0 else (T << -ls)
+        _, ch, _ls = self.taps()[i]
+        Lx = lib().vqvs_debug_tap_rows(self._h, i, T)
+        if Lx < 0:
+            check(Lx)
         out = torch.empty(B, ch, Lx, dtype=torch.float32)
         check(lib().vqvs_debug_read_tap(self._h, i, B, T, out.data_ptr()))
         return out

@@ -109,7 +109,7 @@ static int check_run(vqvs_model* m, int kind, int B, int L) {
   if (B < 1 || B > m->cfg.max_batch) VQVS_FAIL(VQVS_ERR_ARG, "batch %d outside 1..%d", B, m->cfg.max_batch);
   if (L < 1 || L > m->cfg.max_T) VQVS_FAIL(VQVS_ERR_ARG, "length %d outside 1..%d", L, m->cfg.max_T);
   if (kind == VQVS_KIND_CLASSIFIER && (L % 512)) VQVS_FAIL(VQVS_ERR_ARG, "T=%d is not a multiple of the classifier downsample rate 512", L);
-  if (kind != VQVS_KIND_RESBLOCK && (L % 256)) VQVS_FAIL(VQVS_ERR_ARG, "T=%d is not a multiple of the UNet downsample rate 256", L);
+  if (kind != VQVS_KIND_RESBLOCK && kind != VQVS_KIND_MFCC_ENCODER && (L % 256)) VQVS_FAIL(VQVS_ERR_ARG, "T=%d is not a multiple of the UNet downsample rate 256", L);
   if (kind == VQVS_KIND_RESBLOCK && m->cfg.rb_resize == RESIZE_AVG2 && (L % 2)) VQVS_FAIL(VQVS_ERR_ARG, "avg-pool resblock needs even L");
   return 0;
 }
@@ -136,6 +136,19 @@ int vqvs_unet_forward(vqvs_model* m, const float* d_x, const float* d_ts, const 
 int vqvs_encoder_forward(vqvs_model* m, const float* d_x, float* d_z, int B, int T, void* stream) {
   if (int e = check_run(m, VQVS_KIND_ENCODER, B, T)) return e;
   if (!d_x || !d_z) VQVS_FAIL(VQVS_ERR_ARG, "x and z must be non-NULL");
+  RunCtx c;
+  c.B = B;
+  c.Lbase = T;
+  c.x = d_x;
+  c.out = d_z;
+  c.st = reinterpret_cast<hipStream_t>(stream);
+  return run_model(m, c);
+}
+
+int vqvs_mfcc_encoder_forward(vqvs_model* m, const float* d_x, float* d_z, int B, int T, void* stream) {
+  if (int e = check_run(m, VQVS_KIND_MFCC_ENCODER, B, T)) return e;
+  if (!d_x || !d_z) VQVS_FAIL(VQVS_ERR_ARG, "x and z must be non-NULL");
+  if (T < 800) VQVS_FAIL(VQVS_ERR_ARG, "T=%d is too short for the MFCC front end (needs at least 800 samples)", T);
   RunCtx c;
   c.B = B;
   c.Lbase = T;
@@ -285,11 +298,16 @@ int vqvs_debug_tap_info(const vqvs_model* m, int i, char* name_out, int name_cap
   return 0;
 }
 
+int vqvs_debug_tap_rows(const vqvs_model* m, int i, int T) {
+  if (!m || i < 0 || i >= (int)m->taps.size()) VQVS_FAIL(VQVS_ERR_ARG, "bad tap index");
+  return tensor_rows(T, m->taps[i].t.lshift);
+}
+
 int vqvs_debug_read_tap(vqvs_model* m, int i, int B, int T, float* h_out) {
   if (!m || i < 0 || i >= (int)m->taps.size() || !h_out) VQVS_FAIL(VQVS_ERR_ARG, "bad argument");
   if (!m->cfg.debug_taps) VQVS_FAIL(VQVS_ERR_STATE, "model was not created with debug_taps=1");
   const TensorH& t = m->taps[i].t;
-  const int L = t.lshift >= 0 ? (T >> t.lshift) : (T << -t.lshift);
+  const int L = tensor_rows(T, t.lshift);
   const size_t n = (size_t)B * t.C * L;
   float* d_tmp = nullptr;
   VQVS_HIP(hipSetDevice(m->device));

@@ -532,12 +532,21 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
   TMARK(8)
 
   f32x8 s1 = f32x8_zero(), s2 = f32x8_zero();
+  const int out_rows = a.out_rows ? a.out_rows : a.Lout;
 #pragma unroll
   for (int i = 0; i < NEP; ++i) {
     const int r = r0 + RPP * i;
     const int tm = t0 + r;
     if (r < TTO && tm < a.Lout) {
       f32x8 v = Elem<float>::load8(ost + r * OS + eoct * 8);
+      if (a.epi_gelu) {
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          const f32x2 g = gelu2<GQ>(f32x2{v[j], v[j + 1]});
+          v[j] = g[0];
+          v[j + 1] = g[1];
+        }
+      }
       if (skip_pf) {
         v += rsk[SKIP_PF ? i : 0].get();
       } else if (skip_b) {
@@ -550,7 +559,7 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
       }
       s1 += v;
       s2 += v * v;
-      const size_t oidx = ((size_t)b * a.Lout + tm) * a.Cout + cg;
+      const size_t oidx = ((size_t)b * out_rows + tm) * a.Cout + cg;
       if (a.out_f32)
         Elem<float>::store8(reinterpret_cast<float*>(a.out) + oidx, v);
       else

@@ -61,6 +61,8 @@ struct ConvArgs {
   float* stats;   // [B][ntiles][Cout][2] or nullptr
   int ntiles;     // ceil(Lout / tile_rows)
   int tile_rows;  // output rows per workgroup = conv_tile_rows(max dilation of the 3-tap segments)
+  int out_rows;   // rows per clip of the output allocation (0 = Lout); > Lout leaves padding rows untouched
+  int epi_gelu;   // 1: out = skip + gelu(acc) -- the ResConv / Conv+GELU blocks of ConvMFCCEncoder (conv_encoder.py:60-84, 113-120)
 };
 
 int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st);
@@ -74,8 +76,8 @@ struct InConvArgs {  // Conv1d(1 -> C, k=3, pad=1) (+ nearest-upsampled cond pro
   const float* x;    // [B][T]
   const float* w;    // [C][3]
   const float* bias; // [C]
-  const void* condp; // [B][T/cond_rate][C] of T or nullptr
-  int cond_rate;
+  const void* condp; // [B][cond_len][C] of T or nullptr: added as F.interpolate(cond, T) (nearest), unet.py:139
+  int cond_len;      // rows of condp per clip (T/256 behind a UNet encoder, T/320 behind the MFCC encoder)
   void* out;         // [B][T][C] of T
   float* stats;      // [B][ntiles][C][2]
   int C, T, ntiles;
@@ -234,6 +236,31 @@ struct EncHeadArgs {
   int Cb, D, T, T1, rate;
 };
 int launch_enc_head(const EncHeadArgs& a, int B, int precision, hipStream_t st);
+
+// ----------------------------------------------------------------------------------
+// MFCC front end of ConvMFCCEncoder (conv_encoder.py:42-58, 96-104; torchaudio.transforms.MFCC restated, see mfcc_kernels.hip)
+// ----------------------------------------------------------------------------------
+struct MfccArgs {
+  const float* x;         // [B][T] waveform (mu-law companded when ulaw)
+  const double* twiddle;  // [n_fft][2]: cos, -sin of 2 pi n / n_fft
+  const float* window;    // [n_fft]            buffer mfcc.MelSpectrogram.spectrogram.window
+  const float* fb;        // [n_freqs][n_mels]  buffer mfcc.MelSpectrogram.mel_scale.fb
+  float* logmel;          // out [B][frames][n_mels]: log(mel + 1e-6) or 10 log10(max(mel, 1e-10))
+  float* wgmax;           // out per-workgroup maximum [B][groups] (dB variant) or nullptr
+  int T, n_fft, hop, n_freqs, n_mels, frames, ulaw, log_mels;
+  double power_scale;     // 1 / sum(window^2) when the spectrogram is normalized, else 1
+};
+int launch_mfcc_logmel(const MfccArgs& a, int B, hipStream_t st);
+int mfcc_groups(int frames);
+int launch_mfcc_batch_max(const float* wgmax, int n, float* out, hipStream_t st);
+struct MfccFeatArgs {
+  const float* logmel;     // [B][frames][n_mels]
+  const float* dct;        // [n_mels][13]       buffer mfcc.dct_mat
+  const float* batch_max;  // [1] maximum of logmel over the batch (dB variant: values are floored at max - 80) or nullptr
+  float* feat;             // out [B][rows_alloc][64]
+  int frames, rows_alloc, n_mels;
+};
+int launch_mfcc_features(const MfccFeatArgs& a, int B, hipStream_t st);
 
 // layout changes at the library boundary (reference tensors are NCT float32)
 int launch_nct_to_ntc(const float* in, void* out, float* stats, int B, int C, int L, int ntiles, int precision, hipStream_t st);

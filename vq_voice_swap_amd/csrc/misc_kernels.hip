@@ -34,6 +34,8 @@ __global__ __launch_bounds__(256) void in_conv_kernel(const InConvArgs a) {
   const float* xb = a.x + (size_t)b * a.T;
   f32x8 s1 = f32x8_zero(), s2 = f32x8_zero();
   const bool active = r0 < rpp && oct < opr;
+  // nearest-neighbour source row exactly as PyTorch's upsample_nearest1d computes it: min(floor(dst * (float)in / out), in - 1)
+  const float cond_scale = a.condp ? (float)a.cond_len / (float)a.T : 0.f;
   if (active) {
     for (int r = r0; r < STAT_TILE; r += rpp) {
       const int t = t0 + r;
@@ -45,7 +47,8 @@ __global__ __launch_bounds__(256) void in_conv_kernel(const InConvArgs a) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = fmaf(w2[j], xp, fmaf(w1[j], x0, fmaf(w0[j], xm, bs[j])));
       if (a.condp) {
-        const T* cp = reinterpret_cast<const T*>(a.condp) + ((size_t)b * (a.T / a.cond_rate) + t / a.cond_rate) * a.C + c;
+        const int cr = min((int)floorf((float)t * cond_scale), a.cond_len - 1);
+        const T* cp = reinterpret_cast<const T*>(a.condp) + ((size_t)b * a.cond_len + cr) * a.C + c;
         v += Elem<T>::load8(cp);
       }
       s1 += v;

@@ -180,8 +180,27 @@ std::vector<float> transpose_flip(const float* W, int Cout, int Cin, int ktaps) 
   return t;
 }
 
-double lscale(int lshift) { return lshift >= 0 ? 1.0 / (double)(1 << lshift) : (double)(1 << -lshift); }
-int shiftL(int L, int lshift) { return lshift >= 0 ? (L >> lshift) : (L << -lshift); }
+// A tensor's length is a function of the base length of the run.  UNets: a power-of-two shift.  ConvMFCCEncoder
+// (conv_encoder.py:44-58, 65-71): lengths derived from the MFCC frame count T / hop + 1, encoded as lshift >= LEN_FRAMES.
+constexpr int MFCC_HOP = 160;     // input_rate / mfcc_rate = 16000 / 100 (conv_encoder.py:29-30, never changed by make_encoder)
+constexpr int LEN_FRAMES = 100;   // T / hop + 1                      (torch.stft, center=True)
+constexpr int LEN_FRAMES_PAD = 101;  // frames rounded up to even: allocation of the tensor the stride-2 convolution reads
+constexpr int LEN_PAIRS = 102;    // LEN_FRAMES_PAD / 2: rows of that tensor viewed as [pairs][2 * channels]
+constexpr int LEN_HALF = 103;     // (frames + 2 - 4) / 2 + 1: output length of Conv1d(k = 4, stride = 2, padding = 1)
+double lscale(int lshift) {
+  if (lshift >= LEN_FRAMES) return (lshift == LEN_PAIRS || lshift == LEN_HALF ? 0.5 : 1.0) / MFCC_HOP;
+  return lshift >= 0 ? 1.0 / (double)(1 << lshift) : (double)(1 << -lshift);
+}
+int shiftL(int L, int lshift) {
+  if (lshift >= LEN_FRAMES) {
+    const int frames = L / MFCC_HOP + 1;
+    if (lshift == LEN_FRAMES) return frames;
+    if (lshift == LEN_FRAMES_PAD) return (frames + 1) & ~1;
+    if (lshift == LEN_PAIRS) return (frames + 1) >> 1;
+    return (frames - 2) / 2 + 1;
+  }
+  return lshift >= 0 ? (L >> lshift) : (L << -lshift);
+}
 int ntiles_of(int L, int rows = STAT_TILE) { return (L + rows - 1) / rows; }
 constexpr int MIN_TILE_ROWS = 124;  // the smallest statistics tile any producer uses (128-row tiles, dilation 2)
 
@@ -334,8 +353,9 @@ class Builder {
     long long w_off;
   };
 
+  // out_lshift: logical output length when it differs from the allocation of `out` (padding rows); epi_gelu: out = skip + gelu(acc)
   void add_conv(const std::vector<SegSpec>& segs, const PackedConv& pk, const std::vector<float>& bias, int Cout, const TensorH& out,
-                const TensorH* skip, int skip_resize) {
+                const TensorH* skip, int skip_resize, int out_lshift = -1000, bool epi_gelu = false) {
     const size_t hi_off = blob.add(pk.hi.data(), pk.hi.size() * 2);
     const size_t lo_off = m_->cfg.precision == VQVS_PREC_F32 ? blob.add(pk.lo.data(), pk.lo.size() * 2) : 0;
     const size_t bias_off = blob.add(bias.data(), bias.size() * 4);
@@ -390,7 +410,9 @@ class Builder {
       a.w_bytes = w_bytes;
       a.bias = reinterpret_cast<const float*>(self->wp(bias_off));
       a.Cout = Cout;
-      a.Lout = shiftL(c.Lbase, O.lshift);
+      a.Lout = shiftL(c.Lbase, out_lshift == -1000 ? O.lshift : out_lshift);
+      a.out_rows = shiftL(c.Lbase, O.lshift);
+      a.epi_gelu = epi_gelu ? 1 : 0;
       if (has_skip) {
         a.skip = self->act(K.off);
         a.skip_C = K.C;
@@ -705,6 +727,8 @@ class Builder {
 
 }  // namespace
 
+int tensor_rows(int Lbase, int lshift) { return shiftL(Lbase, lshift); }
+
 int gn_groups(int ch) {  // unet.py:345-349
   int g = 32;
   while (ch % g) g /= 2;
@@ -775,6 +799,24 @@ int enumerate_params(const vqvs_cfg& c, std::vector<ParamDef>& out) {
     out.push_back({"stem.out.1.c_proj.bias", {F}});
     out.push_back({"out.1.weight", {c.num_labels, F}});
     out.push_back({"out.1.bias", {c.num_labels}});
+  } else if (c.kind == VQVS_KIND_MFCC_ENCODER) {  // conv_encoder.py:42-84; buffers of torchaudio.transforms.MFCC first
+    const int version = c.reserved[1];
+    const int n_fft = version == 2 ? 400 : 2 * MFCC_HOP, n_mels = version == 2 ? 80 : 40, mid = 12 * base;
+    out.push_back({"mfcc.dct_mat", {n_mels, 13}});
+    out.push_back({"mfcc.MelSpectrogram.spectrogram.window", {n_fft}});
+    out.push_back({"mfcc.MelSpectrogram.mel_scale.fb", {n_fft / 2 + 1, n_mels}});
+    out.push_back({"blocks.0.0.weight", {mid, 39, 3}});
+    out.push_back({"blocks.0.0.bias", {mid}});
+    out.push_back({"blocks.1.conv.weight", {mid, mid, 3}});
+    out.push_back({"blocks.1.conv.bias", {mid}});
+    out.push_back({"blocks.2.0.weight", {mid, mid, 4}});
+    out.push_back({"blocks.2.0.bias", {mid}});
+    for (int i = 3; i <= 8; ++i) {
+      out.push_back({"blocks." + std::to_string(i) + ".conv.weight", {mid, mid, i <= 4 ? 3 : 1}});
+      out.push_back({"blocks." + std::to_string(i) + ".conv.bias", {mid}});
+    }
+    out.push_back({"blocks.9.weight", {c.out_channels, mid, 1}});
+    out.push_back({"blocks.9.bias", {c.out_channels}});
   } else {
     VQVS_FAIL(VQVS_ERR_ARG, "unknown model kind %d", c.kind);
   }
@@ -794,6 +836,13 @@ static int check_cfg(const vqvs_cfg& c) {
   // the reference's configurations are 32 and 64; wider bases would need GroupNorm over > 1024 concatenated channels
   if (c.base_channels != 32 && c.base_channels != 64) VQVS_FAIL(VQVS_ERR_ARG, "base_channels must be 32 or 64 (got %d)", c.base_channels);
   if (c.in_channels != 1) VQVS_FAIL(VQVS_ERR_ARG, "in_channels must be 1 (got %d)", c.in_channels);
+  if (c.kind == VQVS_KIND_MFCC_ENCODER) {
+    if (c.precision != VQVS_PREC_F32) VQVS_FAIL(VQVS_ERR_ARG, "the MFCC encoder feeds the VQ layer (bit-exact indices): fp32 precision only");
+    if (c.reserved[1] != 1 && c.reserved[1] != 2) VQVS_FAIL(VQVS_ERR_ARG, "ConvMFCCEncoder version must be 1 or 2 (got %d)", c.reserved[1]);
+    if (c.out_channels % 32 || c.out_channels < 32) VQVS_FAIL(VQVS_ERR_ARG, "encoder out_channels must be a multiple of 32");
+    if (c.max_T < 2 * 400) VQVS_FAIL(VQVS_ERR_ARG, "max_T must be at least 800 samples");
+    return 0;
+  }
   if (c.max_T % 256) VQVS_FAIL(VQVS_ERR_ARG, "max_T must be a multiple of 256 (got %d)", c.max_T);
   // the kernels address rows of one clip with 32-bit byte offsets (buffer loads): the widest per-clip tensor must stay below 2 GiB
   if ((long long)c.max_T * c.base_channels * 8 > 0x7fffffffLL)
@@ -801,6 +850,7 @@ static int check_cfg(const vqvs_cfg& c) {
   if (c.kind == VQVS_KIND_PREDICTOR) {
     if (c.out_channels != 1 && (c.out_channels % 32)) VQVS_FAIL(VQVS_ERR_ARG, "out_channels must be 1 or a multiple of 32");
     if (c.cond_channels % 32) VQVS_FAIL(VQVS_ERR_ARG, "cond_channels must be a multiple of 32");
+    if (c.reserved[3] != 0 && c.reserved[3] != 1) VQVS_FAIL(VQVS_ERR_ARG, "cond length code (reserved[3]) must be 0 (T/256) or 1 (T/320)");
   } else if (c.kind == VQVS_KIND_ENCPRED) {
     if (c.out_channels % 32 || c.out_channels < 32 || c.out_channels > 256) VQVS_FAIL(VQVS_ERR_ARG, "bottleneck_dim must be a multiple of 32 in 32..256");
     if (c.cond_channels) VQVS_FAIL(VQVS_ERR_ARG, "the encoder predictor's UNet is unconditional");
@@ -930,13 +980,15 @@ int build_model(vqvs_model* m, const float* const* hp) {
     TensorH condp{};
     const bool has_cond = c.cond_channels > 0;
     if (has_cond) {
-      TensorH ct = b.new_tensor(c.cond_channels, 8, false, false);
+      // conditioning rows per clip: T / 256 behind a UNet encoder, (T / 160 + 1 - 2) / 2 + 1 = T / 320 behind the MFCC encoder
+      const int cond_ls = c.reserved[3] == 1 ? LEN_HALF : 8;
+      TensorH ct = b.new_tensor(c.cond_channels, cond_ls, false, false);
       const int CC = c.cond_channels;
       m->meta.push_back({"nct_to_ntc", "", 0, 0, 0});
       m->add_op([=](const RunCtx& r) -> int {
-        return launch_nct_to_ntc(r.cond, bp->act(ct.off), nullptr, r.B, CC, r.Lbase >> 8, 0, prec, r.st);
+        return launch_nct_to_ntc(r.cond, bp->act(ct.off), nullptr, r.B, CC, shiftL(r.Lbase, cond_ls), 0, prec, r.st);
       });
-      condp = b.new_tensor(base, 8, false, false);
+      condp = b.new_tensor(base, cond_ls, false, false);
       PackedConv pk(prec);
       Builder::SegSpec g{ct, 0, CC, 3, 1, RESIZE_NONE, false, 0, 0, 0, 0};
       g.w_off = pk.append(b.P(px + "cond_proj.weight"), base, CC, 3, 0, CC);
@@ -949,14 +1001,14 @@ int build_model(vqvs_model* m, const float* const* hp) {
     {
       const size_t w = b.blob_f32(px + "in_conv.weight"), bi = b.blob_f32(px + "in_conv.bias");
       const TensorH cp = condp;
-      m->meta.push_back({"in_conv", "1->" + std::to_string(base), base + (has_cond ? base / 256.0 : 0.0), 4.0, 0});
+      m->meta.push_back({"in_conv", "1->" + std::to_string(base), base + (has_cond ? base * lscale(condp.lshift) : 0.0), 4.0, 0});
       m->add_op([=](const RunCtx& r) -> int {
         InConvArgs a{};
         a.x = r.x;
         a.w = reinterpret_cast<const float*>(bp->wp(w));
         a.bias = reinterpret_cast<const float*>(bp->wp(bi));
         a.condp = has_cond ? bp->act(cp.off) : nullptr;
-        a.cond_rate = 256;
+        a.cond_len = has_cond ? shiftL(r.Lbase, cp.lshift) : 0;
         a.out = bp->act(h.off);
         a.stats = bp->statp(h.stats_off);
         a.C = base;
@@ -1164,7 +1216,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
       a.w = reinterpret_cast<const float*>(bp->wp(inw));
       a.bias = reinterpret_cast<const float*>(bp->wp(inb));
       a.condp = nullptr;
-      a.cond_rate = 256;
+      a.cond_len = 0;
       a.out = bp->act(h.off);
       a.stats = bp->statp(h.stats_off);
       a.C = base;
@@ -1256,6 +1308,138 @@ int build_model(vqvs_model* m, const float* const* hp) {
       });
     }
     m->cur_phase = 0;
+  } else if (c.kind == VQVS_KIND_MFCC_ENCODER) {
+    // ConvMFCCEncoder.forward (conv_encoder.py:90-110).  The convolution stack runs on the fused MFMA kernel in the fp32
+    // mode: every layer is a raw segment with the GELU in the EPILOGUE (out = skip + gelu(conv(x)), conv_encoder.py:113-120);
+    // Conv1d(k = 4, stride = 2, padding = 1) is a 3-tap stride-1 convolution over the input viewed as [pairs][2 * mid]:
+    //   out[t] = W0 x[2t-1] + W1 x[2t] + W2 x[2t+1] + W3 x[2t+2]  =  sum over taps j = -1, 0, +1 of pair rows t + j with
+    //   even half: (0, W1, W3), odd half: (W0, W2, 0).
+    const int version = c.reserved[1], ulaw = c.reserved[2] ? 1 : 0;
+    const int n_fft = version == 2 ? 400 : 2 * MFCC_HOP, n_mels = version == 2 ? 80 : 40, n_freqs = n_fft / 2 + 1, mid = 12 * base;
+    const int OC = c.out_channels;
+    std::vector<double> tw(2 * (size_t)n_fft);
+    for (int n = 0; n < n_fft; ++n) {
+      tw[2 * n] = std::cos(2.0 * M_PI * n / n_fft);
+      tw[2 * n + 1] = -std::sin(2.0 * M_PI * n / n_fft);
+    }
+    const size_t tw_off = b.blob.add(tw.data(), tw.size() * 8);
+    const size_t win_off = b.blob_f32("mfcc.MelSpectrogram.spectrogram.window"), fb_off = b.blob_f32("mfcc.MelSpectrogram.mel_scale.fb");
+    const size_t dct_off = b.blob_f32("mfcc.dct_mat");
+    double wss = 0.0;
+    for (int n = 0; n < n_fft; ++n) wss += (double)b.P("mfcc.MelSpectrogram.spectrogram.window")[n] * (double)b.P("mfcc.MelSpectrogram.spectrogram.window")[n];
+    const double power_scale = version == 2 ? 1.0 / wss : 1.0;  // Spectrogram(normalized=True): spec / sqrt(sum w^2), then |.|^2
+    const int max_frames = c.max_T / MFCC_HOP + 1;
+    const size_t logmel_off = b.alloc_misc((size_t)c.max_batch * max_frames * n_mels);
+    const size_t wgmax_off = b.alloc_misc((size_t)c.max_batch * mfcc_groups(max_frames) + 64);
+    const bool db = version == 2;
+    TensorH feat = b.new_tensor(64, LEN_FRAMES, false, false);  // fp32 handle: the activation type is float
+    m->meta.push_back({"mfcc_logmel", "n_fft=" + std::to_string(n_fft) + " mels=" + std::to_string(n_mels), 0, 4.0, 0});
+    m->add_op([=](const RunCtx& r) -> int {
+      MfccArgs a{};
+      a.x = r.x;
+      a.twiddle = reinterpret_cast<const double*>(bp->wp(tw_off));
+      a.window = reinterpret_cast<const float*>(bp->wp(win_off));
+      a.fb = reinterpret_cast<const float*>(bp->wp(fb_off));
+      a.logmel = bp->miscp(logmel_off);
+      a.wgmax = db ? bp->miscp(wgmax_off) + 64 : nullptr;
+      a.T = r.Lbase;
+      a.n_fft = n_fft;
+      a.hop = MFCC_HOP;
+      a.n_freqs = n_freqs;
+      a.n_mels = n_mels;
+      a.frames = shiftL(r.Lbase, LEN_FRAMES);
+      a.ulaw = ulaw;
+      a.log_mels = db ? 0 : 1;
+      a.power_scale = power_scale;
+      if (int e = launch_mfcc_logmel(a, r.B, r.st)) return e;
+      if (db) return launch_mfcc_batch_max(bp->miscp(wgmax_off) + 64, r.B * mfcc_groups(a.frames), bp->miscp(wgmax_off), r.st);
+      return 0;
+    });
+    m->meta.push_back({"mfcc_features", "13 x 3 -> 64 channels", 64.0 / MFCC_HOP, 0, 0});
+    m->add_op([=](const RunCtx& r) -> int {
+      MfccFeatArgs a{};
+      a.logmel = bp->miscp(logmel_off);
+      a.dct = reinterpret_cast<const float*>(bp->wp(dct_off));
+      a.batch_max = db ? bp->miscp(wgmax_off) : nullptr;
+      a.feat = reinterpret_cast<float*>(bp->act(feat.off));
+      a.frames = shiftL(r.Lbase, LEN_FRAMES);
+      a.rows_alloc = a.frames;
+      a.n_mels = n_mels;
+      return launch_mfcc_features(a, r.B, r.st);
+    });
+    b.tap("features", feat);
+    auto conv_layer = [&](const TensorH& in, int in_C, int in_lshift, const std::vector<float>& W, int cout, int cin, int ktaps,
+                          const float* bias, const TensorH& out, int out_lshift, const TensorH* skip, bool gelu) {
+      TensorH view = in;
+      view.C = in_C;
+      view.lshift = in_lshift;
+      PackedConv pk(prec);
+      Builder::SegSpec g{view, 0, in_C, ktaps, 1, RESIZE_NONE, false, 0, 0, 0, 0};
+      g.w_off = pk.append(W.data(), cout, cin, ktaps, 0, in_C);
+      b.add_conv({g}, pk, std::vector<float>(bias, bias + cout), cout, out, skip, RESIZE_NONE, out_lshift, gelu);
+    };
+    auto wvec = [&](const std::string& name, size_t n) { return std::vector<float>(b.P(name), b.P(name) + n); };
+    // blocks.0: Conv1d(39 -> mid, 3) + GELU over the zero-padded 64-channel feature rows
+    TensorH h0 = b.new_tensor(mid, LEN_FRAMES, false, false);
+    {
+      std::vector<float> W((size_t)mid * 64 * 3, 0.f);
+      const float* w = b.P("blocks.0.0.weight");
+      for (int co = 0; co < mid; ++co)
+        for (int ci = 0; ci < 39; ++ci)
+          for (int k = 0; k < 3; ++k) W[((size_t)co * 64 + ci) * 3 + k] = w[((size_t)co * 39 + ci) * 3 + k];
+      conv_layer(feat, 64, LEN_FRAMES, W, mid, 64, 3, b.P("blocks.0.0.bias"), h0, LEN_FRAMES, nullptr, true);
+    }
+    b.release(feat);
+    b.tap("blocks.0", h0);
+    // blocks.1: ResConv(3), written into an allocation with an even number of rows (last row zero)
+    TensorH h1 = b.new_tensor(mid, LEN_FRAMES_PAD, false, false);
+    {
+      const TensorH hp = h1;
+      m->meta.push_back({"pad_row", "", 0, 0, 0});
+      m->add_op([=](const RunCtx& r) -> int {
+        const int frames = shiftL(r.Lbase, LEN_FRAMES), rows = shiftL(r.Lbase, LEN_FRAMES_PAD);
+        if (rows == frames) return 0;
+        VQVS_HIP(hipMemset2DAsync(bp->act(hp.off) + (size_t)frames * mid * 4, (size_t)rows * mid * 4, 0, (size_t)mid * 4, r.B, r.st));
+        return 0;
+      });
+    }
+    conv_layer(h0, mid, LEN_FRAMES, wvec("blocks.1.conv.weight", (size_t)mid * mid * 3), mid, mid, 3, b.P("blocks.1.conv.bias"), h1,
+               LEN_FRAMES, &h0, true);
+    b.release(h0);
+    // blocks.2: Conv1d(mid -> mid, 4, stride 2, padding 1) + GELU as a 3-tap convolution over [pairs][2 * mid]
+    TensorH h2 = b.new_tensor(mid, LEN_HALF, false, false);
+    {
+      std::vector<float> W((size_t)mid * 2 * mid * 3, 0.f);
+      const float* w = b.P("blocks.2.0.weight");  // [mid][mid][4]
+      for (int co = 0; co < mid; ++co)
+        for (int ci = 0; ci < mid; ++ci) {
+          const float* wk = w + ((size_t)co * mid + ci) * 4;
+          float* even = &W[((size_t)co * 2 * mid + ci) * 3];
+          float* odd = &W[((size_t)co * 2 * mid + mid + ci) * 3];
+          even[1] = wk[1];  // x[2t]
+          even[2] = wk[3];  // x[2t+2] = even half of pair row t+1
+          odd[0] = wk[0];   // x[2t-1] = odd half of pair row t-1
+          odd[1] = wk[2];   // x[2t+1]
+        }
+      conv_layer(h1, 2 * mid, LEN_PAIRS, W, mid, 2 * mid, 3, b.P("blocks.2.0.bias"), h2, LEN_HALF, nullptr, true);
+    }
+    b.release(h1);
+    b.tap("blocks.2", h2);
+    TensorH h = h2;
+    for (int i = 3; i <= 8; ++i) {  // ResConv(3) x 2, ResConv(1) x 4
+      const int k = i <= 4 ? 3 : 1;
+      TensorH o = b.new_tensor(mid, LEN_HALF, false, false);
+      const std::string nm = "blocks." + std::to_string(i) + ".conv";
+      conv_layer(h, mid, LEN_HALF, wvec(nm + ".weight", (size_t)mid * mid * k), mid, mid, k, b.P(nm + ".bias"), o, LEN_HALF, &h, true);
+      b.release(h);
+      h = o;
+    }
+    b.tap("blocks.8", h);
+    TensorH o = b.new_tensor(OC, LEN_HALF, true, false);
+    conv_layer(h, mid, LEN_HALF, wvec("blocks.9.weight", (size_t)OC * mid), OC, mid, 1, b.P("blocks.9.bias"), o, LEN_HALF, nullptr, false);
+    b.release(h);
+    m->meta.push_back({"ntc_to_nct", "", 0, 0, 0});
+    m->add_op([=](const RunCtx& r) -> int { return launch_ntc_to_nct(bp->act(o.off), r.out, r.B, OC, shiftL(r.Lbase, LEN_HALF), 0, r.st); });
   } else {  // encoder (unet.py:229-241)
     std::vector<BlockSpec> blocks;
     encoder_blocks(base, blocks);
@@ -1269,7 +1453,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
         a.w = reinterpret_cast<const float*>(bp->wp(w));
         a.bias = reinterpret_cast<const float*>(bp->wp(bi));
         a.condp = nullptr;
-        a.cond_rate = 256;
+        a.cond_len = 0;
         a.out = bp->act(h.off);
         a.stats = bp->statp(h.stats_off);
         a.C = base;

@@ -105,4 +105,5 @@ int enumerate_params(const vqvs_cfg& cfg, std::vector<ParamDef>& out);
 int build_model(vqvs_model* m, const float* const* h_params);
 int run_model(vqvs_model* m, const RunCtx& ctx);
 int gn_groups(int ch);
+int tensor_rows(int Lbase, int lshift);  // rows per clip of a tensor with length code `lshift` at base length Lbase
 }  // namespace vqvs

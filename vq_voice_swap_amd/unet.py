@@ -198,6 +198,7 @@ class UNetPredictor(_NativeModule):
         self.in_channels = in_channels
         self.out_channels = out_channels
         self.dropout = dropout
+        self._cond_code = 0  # conditioning rows per clip: 0 = T / 256 (UNet encoder), 1 = T / 320 (ConvMFCCEncoder)
 
         C = base_channels
         E = 4 * C
@@ -243,6 +244,7 @@ class UNetPredictor(_NativeModule):
         cfg.cond_channels = self.cond_channels or 0
         cfg.num_labels = self.num_labels or 0
         cfg.reserved[0] = 1 if self.dropout else 0
+        cfg.reserved[3] = self._cond_code
         return cfg
 
     def forward(self, x: torch.Tensor, ts: torch.Tensor, cond: Optional[torch.Tensor] = None,
@@ -262,8 +264,14 @@ class UNetPredictor(_NativeModule):
             raise ValueError(f"expected ts of shape [{B}], got {tuple(ts.shape)}")
         if cond is not None:
             cond = cond.detach().to(torch.float32).contiguous()
-            if tuple(cond.shape) != (B, self.cond_channels, T // 256):
-                raise ValueError(f"expected cond of shape {(B, self.cond_channels, T // 256)}, got {tuple(cond.shape)}")
+            # the reference up-samples ANY cond length to T (F.interpolate, unet.py:139); the library knows the two lengths
+            # its encoders produce: T / 256 (UNetEncoder) and (T / 160 + 1 - 2) / 2 + 1 = T / 320 (ConvMFCCEncoder)
+            lens = {T // 256: 0, (T // 160 + 1 - 2) // 2 + 1: 1}
+            if tuple(cond.shape[:2]) != (B, self.cond_channels) or cond.shape[2] not in lens:
+                raise ValueError(f"expected cond of shape {(B, self.cond_channels)} x {sorted(lens)}, got {tuple(cond.shape)}")
+            if lens[cond.shape[2]] != self._cond_code:
+                self._cond_code = lens[cond.shape[2]]
+                self.invalidate()
         if labels is not None:
             labels = labels.detach().to(device=x.device, dtype=torch.int64).contiguous()
             if labels.shape != (B,):

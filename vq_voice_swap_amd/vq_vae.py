@@ -12,14 +12,23 @@ import torch
 
 from .diffusion import randn_clips
 from .diffusion_model import DiffusionModel
+from .conv_encoder import ConvMFCCEncoder
 from .unet import UNetEncoder
 from .vq import VQ
 
 
 def make_encoder(enc_name: str, base_channels: int = 32, cond_mult: int = 16):
+    """reference models/make.py:41-84: the UNet encoder and the three ConvMFCCEncoder variants are built."""
     if enc_name == "unet":
         return UNetEncoder(base_channels=base_channels, out_channels=base_channels * cond_mult)
-    raise ValueError(f"encoder {enc_name!r} is outside the accelerated hot path (SURVEY.md section 2a); only 'unet' is built")
+    if enc_name == "conv-mfcc-ulaw":
+        return ConvMFCCEncoder(base_channels=base_channels, out_channels=base_channels * cond_mult)
+    if enc_name == "conv-mfcc-ulaw-v2":
+        return ConvMFCCEncoder(base_channels=base_channels, out_channels=base_channels * cond_mult, version=2)
+    if enc_name == "conv-mfcc-linear":
+        return ConvMFCCEncoder(base_channels=base_channels, out_channels=base_channels * cond_mult, input_ulaw=False)
+    raise ValueError(f"encoder {enc_name!r} is outside the accelerated hot path (SURVEY.md section 2a): "
+                     "'unet' and the 'conv-mfcc-*' encoders are built")
 
 
 class VQVAE(DiffusionModel):
@@ -37,7 +46,7 @@ class VQVAE(DiffusionModel):
         """Precision of the diffusion decoder; the encoder stays in the fp32 mode unless asked otherwise, because VQ code
         indices have to be bit-exact (a 2-byte encoder flips near-tie codes: 23/500 in bf16) and it runs once per clip."""
         self.predictor.set_precision(precision)
-        self.encoder.set_precision(encoder_precision)
+        self.encoder.set_precision(encoder_precision)  # (ConvMFCCEncoder accepts fp32 only)
         return self
 
     def encode(self, inputs: torch.Tensor) -> torch.Tensor:
