@@ -35,7 +35,7 @@ def arg_parser():
     p.add_argument("--schedule", default="lambda t: t", type=str)
     p.add_argument("--encoding", default="linear", type=str)
     p.add_argument("--seed", default=None, type=int)
-    p.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
+    p.add_argument("--precision", default="fp32", choices=["fp32", "fp16", "bf16"])
     return p
 
 
@@ -55,9 +55,14 @@ def sample_batch(args, model, classifier, device, n, seed, clip_offset, schedule
         pred = lambda xs, ts, _l=labels: model.predictor(xs, ts, labels=_l)  # noqa: E731
     cond_fn = None
     if classifier is not None:  # reference sample_diffusion.py:34-42, 108-114
-        if labels is None:
-            labels = sample_labels(args, classifier.num_labels, n, device, gen)
-        cond_fn = classifier.guidance_fn(labels, args.classifier_scale)
+        if labels is not None:
+            cond_fn = classifier.guidance_fn(labels, args.classifier_scale)
+        else:
+            # unconditional model: the reference draws the guidance labels afresh on EVERY cond_fn call
+            # (sample_diffusion.py:34-36) -- constant only with --target-class
+            def cond_fn(x, ts):
+                return classifier.log_prob_grad(x, ts, sample_labels(args, classifier.num_labels, len(ts), ts.device, gen),
+                                                args.classifier_scale)
     return model.diffusion.ddpm_sample(x_T, pred, args.sample_steps, progress=n == 1, constrain=args.constrain,
                                        cond_fn=cond_fn, schedule=schedule, seed=seed, clip_offset=clip_offset)
 

@@ -31,7 +31,7 @@ def arg_parser():
     p.add_argument("--no-vq", action="store_true")
     p.add_argument("--check-vq", action="store_true")
     p.add_argument("--seed", default=None, type=int)
-    p.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
+    p.add_argument("--precision", default="fp32", choices=["fp32", "fp16", "bf16"])
     p.add_argument("checkpoint_path", type=str)
     p.add_argument("output_file", type=str)
     return p
@@ -61,7 +61,8 @@ def main(argv=None):
         chunk = reader.read(args.seconds * args.sample_rate)
     finally:
         reader.close()
-    usable = (len(chunk) // 256) * 256  # UNet downsample rate (the reference assumes 4 s = 64000 = 250 * 256)
+    rate = model.downsample_rate  # 256 behind a UNet encoder, lcm(256, 320) = 1280 behind the MFCC encoder (4 s = 64000 fits both)
+    usable = (len(chunk) // rate) * rate
     in_seq = torch.from_numpy(chunk[None, None, :usable]).to(device)
 
     print("encoding audio sequence...")

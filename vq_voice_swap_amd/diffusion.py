@@ -108,18 +108,23 @@ class Diffusion:
         """x_{t-step} ~ p(. | x_t) (reference diffusion.py:48-90).  `noise=None` draws from the
         in-kernel generator keyed by (seed, clip_offset + row, step_index)."""
         _native.require_cuda(x_t, epsilon_prediction, noise)
+        ts = ts.detach().to(device=x_t.device, dtype=torch.float32)
+        if not torch.is_tensor(step):
+            step = torch.full_like(ts, float(step))
+        step = step.to(ts)
+        return self._step(x_t, epsilon_prediction, self.schedule(ts).contiguous(), self.schedule(ts - step).contiguous(), ts - step,
+                          noise=noise, sigma_large=sigma_large, constrain=constrain, cond_fn=cond_fn, seed=seed, clip_offset=clip_offset,
+                          step_index=step_index, noise_scale=noise_scale)
+
+    def _step(self, x_t, epsilon_prediction, a_t, a_prev, ts_prev, *, noise, sigma_large, constrain, cond_fn, seed, clip_offset,
+              step_index, noise_scale) -> torch.Tensor:
+        """The reverse step given alpha_bar(t) and alpha_bar(t - step) as [B] device tensors."""
         if x_t.dim() < 2:
             raise ValueError("x_t must be [N, ..., T]")
         B = x_t.shape[0]
         T = x_t[0].numel()
         x = x_t.detach().to(torch.float32).contiguous()
         eps = epsilon_prediction.detach().to(torch.float32).contiguous()
-        ts = ts.detach().to(device=x.device, dtype=torch.float32)
-        if not torch.is_tensor(step):
-            step = torch.full_like(ts, float(step))
-        step = step.to(ts)
-        a_t = self.schedule(ts).contiguous()
-        a_prev = self.schedule(ts - step).contiguous()
         flags = (_native.DDPM_SIGMA_LARGE if sigma_large else 0) | (_native.DDPM_CONSTRAIN if constrain else 0)
         L = _native.lib()
         st = _native._stream_ptr()
@@ -127,7 +132,7 @@ class Diffusion:
             if cond_fn is not None:  # diffusion.py:80-83
                 mean = torch.empty_like(x)
                 _native.check(L.vqvs_ddpm_mean(x.data_ptr(), eps.data_ptr(), a_t.data_ptr(), a_prev.data_ptr(), mean.data_ptr(), B, T, st))
-                grad = cond_fn(mean.view_as(x_t), ts - step).detach().to(torch.float32).contiguous()
+                grad = cond_fn(mean.view_as(x_t), ts_prev).detach().to(torch.float32).contiguous()
                 eps2 = torch.empty_like(x)
                 _native.check(L.vqvs_ddpm_guided_eps(x.data_ptr(), mean.data_ptr(), grad.data_ptr(), a_t.data_ptr(), a_prev.data_ptr(),
                                                      eps2.data_ptr(), B, T, flags, st))
@@ -163,19 +168,28 @@ class Diffusion:
         x_t = x_T
         B = x_T.shape[0]
         t_values = [(i + 1) / steps for i in range(steps)][::-1]
-        its = enumerate(t_values)
-        if progress:
-            from tqdm.auto import tqdm
-
-            its = tqdm(its, total=steps)
-        for i, t in its:
-            ts = torch.tensor([t] * B).to(x_T)
+        # Per-step scalars: the reference's float32 tensor expressions (diffusion.py:107-118, schedule.py:30-41), evaluated once
+        # on the HOST -- the same arithmetic as the CPU reference -- and uploaded as four [steps, B] tables, instead of ~20
+        # device micro-kernels per step.
+        rows = []
+        for t in t_values:
+            ts = torch.tensor([t] * B, dtype=torch.float32)
             t_step = 1 / steps
             if schedule is not None:
                 t_step = schedule(ts) - schedule(ts - 1 / steps)
                 ts = schedule(ts)
+            step = t_step if torch.is_tensor(t_step) else torch.full_like(ts, float(t_step))
+            rows.append((ts, self.schedule(ts), self.schedule(ts - step), ts - step))
+        ts_all, a_t_all, a_prev_all, ts_prev_all = (torch.stack([r[k] for r in rows]).to(torch.float32).contiguous().to(x_T.device)
+                                                    for k in range(4))
+        its = range(steps)
+        if progress:
+            from tqdm.auto import tqdm
+
+            its = tqdm(its, total=steps)
+        for i in its:
             with torch.no_grad():
-                eps = predictor(x_t, ts)
+                eps = predictor(x_t, ts_all[i])
                 last = i + 1 == steps
                 if last or noise is None:
                     nz = None
@@ -183,10 +197,10 @@ class Diffusion:
                     nz = noise(i)
                 else:
                     nz = noise[i]
-                x_t = self.ddpm_previous(
-                    x_t, ts, t_step, eps, noise=nz, sigma_large=sigma_large, constrain=constrain, cond_fn=cond_fn,
-                    seed=seed, clip_offset=clip_offset, step_index=i, noise_scale=0.0 if last else 1.0,
-                )
+                _native.require_cuda(eps, nz)
+                x_t = self._step(x_t, eps, a_t_all[i], a_prev_all[i], ts_prev_all[i], noise=nz, sigma_large=sigma_large,
+                                 constrain=constrain, cond_fn=cond_fn, seed=seed, clip_offset=clip_offset, step_index=i,
+                                 noise_scale=0.0 if last else 1.0)
         return x_t
 
 
