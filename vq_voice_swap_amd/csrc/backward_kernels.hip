@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void in_conv_bw_kernel(const InConvBwArgs a) {
   __syncthreads();
   // forward: h[t][c] += w[c][k] * x[t+k-1]  =>  dx[t] = sum_k p_k[t-k+1];  y[.][r] holds row t0-1+r
   const int t = t0 + tid;
-  if (t < a.T) a.out[(size_t)b * a.T + t] = y[0][tid + 2] + y[1][tid + 1] + y[2][tid];
+  if (t < a.T) a.out[(size_t)b * a.T + t] = (y[0][tid + 2] + y[1][tid + 1] + y[2][tid]) * a.out_scale;
 }
 
 // ------------------------------------------------------------------------------------

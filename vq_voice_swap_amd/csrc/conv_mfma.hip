@@ -533,6 +533,22 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
 
   f32x8 s1 = f32x8_zero(), s2 = f32x8_zero();
   const int out_rows = a.out_rows ? a.out_rows : a.Lout;
+  // fused GELU backward (guidance): this thread's eight output channels read one forward tensor and their (scale, shift)
+  f32x8 bsc = f32x8_zero(), bsh = f32x8_zero();
+  const T* bxf = nullptr;
+  int bxf_C = 0;
+  if (a.nbw) {
+    const int k = (a.nbw == 2 && cg >= a.bw[1].c_begin) ? 1 : 0;
+    bxf_C = a.bw[k].C;
+    bxf = reinterpret_cast<const T*>(a.bw[k].xf) + (size_t)b * a.Lout * bxf_C + (cg - a.bw[k].c_begin);
+    const float2* p = a.bw_ss + (size_t)b * a.bw_ss_stride + cg;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float2 q = p[j];
+      bsc[j] = q.x;
+      bsh[j] = q.y;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < NEP; ++i) {
     const int r = r0 + RPP * i;
@@ -557,8 +573,19 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
           v += Elem<T>::load8(skip_b + (size_t)(a.skip_resize == RESIZE_UP2 ? (tm >> 1) : tm) * a.skip_C);
         }
       }
-      s1 += v;
-      s2 += v * v;
+      if (a.nbw) {  // v <- v * gelu'(u); statistics (sum v, sum v*u)
+        const f32x8 x = Elem<T>::load8(bxf + (size_t)tm * bxf_C);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float u = fmaf(x[j], bsc[j], bsh[j]);
+          v[j] *= gelu_grad_f(u);
+          s1[j] += v[j];
+          s2[j] = fmaf(v[j], u, s2[j]);
+        }
+      } else {
+        s1 += v;
+        s2 += v * v;
+      }
       const size_t oidx = ((size_t)b * out_rows + tm) * a.Cout + cg;
       if (a.out_f32)
         Elem<float>::store8(reinterpret_cast<float*>(a.out) + oidx, v);

@@ -46,6 +46,15 @@ struct SegDesc {
   int ss_stride, ss_c0;
 };
 
+// Fused GELU backward in the epilogue of a transposed convolution (the guidance backward schedule, backward_kernels.hip
+// bw_act): out = acc * gelu'(u), u = xf * scale + shift, and the tile statistics become (sum out, sum out*u) -- the partial
+// sums GroupNorm's backward needs.  Output channels [c_begin, c_begin + C) read forward tensor `xf` ([B][Lout][C] of T); two
+// sources cover the concatenated input of an up block.  (scale, shift) rows are indexed by the OUTPUT channel.
+struct BwActFuse {
+  const void* xf;
+  int C, c_begin;
+};
+
 struct ConvArgs {
   SegDesc seg[3];
   int nseg;
@@ -63,6 +72,10 @@ struct ConvArgs {
   int tile_rows;  // output rows per workgroup = conv_tile_rows(max dilation of the 3-tap segments)
   int out_rows;   // rows per clip of the output allocation (0 = Lout); > Lout leaves padding rows untouched
   int epi_gelu;   // 1: out = skip + gelu(acc) -- the ResConv / Conv+GELU blocks of ConvMFCCEncoder (conv_encoder.py:60-84, 113-120)
+  BwActFuse bw[2];  // fused GELU backward (nbw = 0: off)
+  int nbw;
+  const float2* bw_ss;  // [B][bw_ss_stride] forward (scale, shift), column = output channel
+  int bw_ss_stride;
 };
 
 int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st);
@@ -192,6 +205,7 @@ struct InConvBwArgs {  // dx[b][t] = sum_k sum_c w[c][k] * dh[b][t-k+1][c]   (ba
   const float* w;   // [C][3]
   float* out;       // [B][T] f32
   int C, T;
+  float out_scale;  // the result is multiplied by this (undoes the gradient scaling of the fp16 mode)
 };
 int launch_in_conv_bw(const InConvBwArgs& a, int B, int precision, hipStream_t st);
 

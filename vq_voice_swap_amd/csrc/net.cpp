@@ -353,9 +353,27 @@ class Builder {
     long long w_off;
   };
 
-  // out_lshift: logical output length when it differs from the allocation of `out` (padding rows); epi_gelu: out = skip + gelu(acc)
-  void add_conv(const std::vector<SegSpec>& segs, const PackedConv& pk, const std::vector<float>& bias, int Cout, const TensorH& out,
-                const TensorH* skip, int skip_resize, int out_lshift = -1000, bool epi_gelu = false) {
+  // GELU backward fused into a transposed convolution's epilogue (kernels.hpp BwActFuse): forward tensors covering the output
+  // channels in order, the forward (scale, shift) table and the partial-sum block the GroupNorm backward reads
+  struct BwFuse {
+    std::vector<TensorH> xf;
+    size_t ss_off;
+    int ss_stride;
+    size_t part_off;
+  };
+  static bool bw_fuse_enabled() {
+    static int v = -1;
+    if (v < 0) {
+      const char* e = getenv("VQVS_BW_FUSE");  // 0: keep the separate bw_act kernel (A/B measurements)
+      v = e ? atoi(e) : 1;
+    }
+    return v != 0;
+  }
+
+  // out_lshift: logical output length when it differs from the allocation of `out` (padding rows); epi_gelu: out = skip + gelu(acc).
+  // Returns the rows per workgroup tile (= rows per statistics / partial-sum tile of the output).
+  int add_conv(const std::vector<SegSpec>& segs, const PackedConv& pk, const std::vector<float>& bias, int Cout, const TensorH& out,
+               const TensorH* skip, int skip_resize, int out_lshift = -1000, bool epi_gelu = false, const BwFuse* fuse = nullptr) {
     const size_t hi_off = blob.add(pk.hi.data(), pk.hi.size() * 2);
     const size_t lo_off = m_->cfg.precision == VQVS_PREC_F32 ? blob.add(pk.lo.data(), pk.lo.size() * 2) : 0;
     const size_t bias_off = blob.add(bias.data(), bias.size() * 4);
@@ -380,6 +398,9 @@ class Builder {
       ktot += (double)s.C * s.ntaps;
     }
     if (skip) conv_elems += K.C * lscale(K.lshift);
+    if (fuse) conv_elems += Cout * lscale(out.lshift);  // the forward tensor(s) read by the fused GELU backward
+    const bool has_fuse = fuse != nullptr;
+    const BwFuse F = fuse ? *fuse : BwFuse{};
     if (out.f32) conv_f32 += 4.0 * Cout * lscale(out.lshift);
     else conv_elems += Cout * lscale(out.lshift);
     const double conv_flops = 2.0 * Cout * ktot * lscale(out.lshift);
@@ -424,8 +445,20 @@ class Builder {
       a.stats = O.has_stats ? self->statp(O.stats_off) : nullptr;
       a.ntiles = ntiles_of(a.Lout, tile_rows);
       a.tile_rows = tile_rows;
+      if (has_fuse) {
+        a.nbw = (int)F.xf.size();
+        int c0 = 0;
+        for (int i = 0; i < a.nbw; ++i) {
+          a.bw[i] = BwActFuse{self->act(F.xf[i].off), F.xf[i].C, c0};
+          c0 += F.xf[i].C;
+        }
+        a.bw_ss = reinterpret_cast<const float2*>(self->ssp(F.ss_off));
+        a.bw_ss_stride = F.ss_stride;
+        a.stats = self->statp(F.part_off);
+      }
       return launch_conv(a, c.B, prec, c.st);
     });
+    return tile_rows;
   }
 
   // One reference ResBlock (unet.py:248-316).  `ins` = 1 tensor, or 2 for torch.cat([h, skip], 1).
@@ -543,7 +576,7 @@ class Builder {
       return launch_bw_act(a, c.B, prec, c.st);
     });
   }
-  size_t add_gn_bw(int C, int lshift, size_t part_off, size_t ss_off, size_t mr_off) {
+  size_t add_gn_bw(int C, int lshift, size_t part_off, size_t ss_off, size_t mr_off, int tile_rows = STAT_TILE) {
     const size_t coef = alloc_misc((size_t)maxB_ * C * 4);
     Builder* self = this;
     const int groups = gn_groups(C);
@@ -552,7 +585,7 @@ class Builder {
       GnBwArgs a{};
       const int L = shiftL(c.Lbase, lshift);
       a.partials = self->statp(part_off);
-      a.ntiles = ntiles_of(L);
+      a.ntiles = ntiles_of(L, tile_rows);
       a.C = C;
       a.groups = groups;
       a.inv_count = 1.0 / ((double)(C / groups) * (double)L);
@@ -603,12 +636,13 @@ class Builder {
     });
   }
   // plain convolution of a raw tensor with transposed weights (no prologue, no statistics, zero bias)
-  void add_conv_t(const TensorH& src, const float* W, int Cout_fwd, int Cin_fwd, int ktaps, int dil, const TensorH& out) {
+  int add_conv_t(const TensorH& src, const float* W, int Cout_fwd, int Cin_fwd, int ktaps, int dil, const TensorH& out,
+                 const BwFuse* fuse = nullptr) {
     const std::vector<float> Wt = transpose_flip(W, Cout_fwd, Cin_fwd, ktaps);
     PackedConv pk(m_->cfg.precision);
     SegSpec g{src, 0, Cout_fwd, ktaps, dil, RESIZE_NONE, false, 0, 0, 0, 0};
     g.w_off = pk.append(Wt.data(), Cin_fwd, Cout_fwd, ktaps, 0, Cout_fwd);
-    add_conv({g}, pk, std::vector<float>(Cin_fwd, 0.f), Cin_fwd, out, nullptr, 0);
+    return add_conv({g}, pk, std::vector<float>(Cin_fwd, 0.f), Cin_fwd, out, nullptr, 0, -1000, false, fuse);
   }
 
   // Gradient of one ResBlock with respect to its input(s):
@@ -626,21 +660,26 @@ class Builder {
     // d gelu2 = conv2^T(dout);  du2 = . * gelu'(u2);  d h1 = GN2 backward
     TensorH t1 = new_tensor(cout, out_shift, false, false);
     const std::string c2 = pre + (cfg_dropout(m_->cfg) ? "post_cond.2" : "post_cond.1");
-    add_conv_t(dout, P(c2 + ".weight"), cout, cout, 3, s.dil, t1);
     const size_t pa = alloc_stats(cout, out_shift);
-    add_bw_act(t1, BW_SAME, r.h1, r.ss2, t1, pa);
-    const size_t cf2 = add_gn_bw(cout, out_shift, pa, r.ss2, r.mr2);
+    const bool fuse = bw_fuse_enabled();  // the multiplication by gelu'(u) and its partial sums ride in the convolution's epilogue
+    const BwFuse f2{{r.h1}, r.ss2, cout, pa};
+    const int tr2 = add_conv_t(dout, P(c2 + ".weight"), cout, cout, 3, s.dil, t1, fuse ? &f2 : nullptr);
+    if (!fuse) add_bw_act(t1, BW_SAME, r.h1, r.ss2, t1, pa);
+    const size_t cf2 = add_gn_bw(cout, out_shift, pa, r.ss2, r.mr2, fuse ? tr2 : STAT_TILE);
     add_bw_affine(t1, r.h1, cf2, nullptr, BW_SAME, nullptr, t1);
     // d resize(gelu1) = conv1^T(d h1);  du1 = resize^T(.) * gelu'(u1);  dx = GN1 backward + skip path
     TensorH t2 = new_tensor(cin, out_shift, false, false);
-    add_conv_t(t1, P(pre + "pre_cond.2.weight"), cout, cin, 3, 1, t2);
-    release(t1);
     const size_t pb = alloc_stats(cin, in_shift);
+    const bool fuse1 = fuse && rs == BW_SAME;  // (resizing blocks keep the separate kernel: their gradient changes resolution first)
+    BwFuse f1{{r.x}, r.ss1, cin, pb};
+    if (cat) f1.xf.push_back(r.x2);
+    const int tr1 = add_conv_t(t1, P(pre + "pre_cond.2.weight"), cout, cin, 3, 1, t2, fuse1 ? &f1 : nullptr);
+    release(t1);
     if (!cat) {
       TensorH du1 = rs != BW_SAME ? new_tensor(cin, in_shift, false, false) : t2;
-      add_bw_act(t2, rs, r.x, r.ss1, du1, pb);
+      if (!fuse1) add_bw_act(t2, rs, r.x, r.ss1, du1, pb);
       if (rs != BW_SAME) release(t2);
-      const size_t cf1 = add_gn_bw(cin, in_shift, pb, r.ss1, r.mr1);
+      const size_t cf1 = add_gn_bw(cin, in_shift, pb, r.ss1, r.mr1, fuse1 ? tr1 : STAT_TILE);
       if (cin != cout) {
         TensorH t3 = new_tensor(cin, out_shift, false, false);
         add_conv_t(dout, P(pre + "skip.1.weight"), cout, cin, 1, 1, t3);
@@ -656,11 +695,11 @@ class Builder {
     // take their column slices; GroupNorm 1 runs over the concatenation
     const TensorH srcs[2] = {r.x, r.x2};
     int c0 = 0;
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 2 && !fuse1; ++i) {
       add_bw_act(t2, BW_SAME, srcs[i], r.ss1, t2, pb, c0, cin);
       c0 += srcs[i].C;
     }
-    const size_t cf1 = add_gn_bw(cin, in_shift, pb, r.ss1, r.mr1);
+    const size_t cf1 = add_gn_bw(cin, in_shift, pb, r.ss1, r.mr1, fuse1 ? tr1 : STAT_TILE);
     TensorH t3 = new_tensor(cin, out_shift, false, false);
     add_conv_t(dout, P(pre + "skip.1.weight"), cout, cin, 1, 1, t3);
     release(dout);
@@ -728,6 +767,11 @@ class Builder {
 }  // namespace
 
 int tensor_rows(int Lbase, int lshift) { return shiftL(Lbase, lshift); }
+
+// The guidance gradients d log p / d activation are O(1e-6 ... 1e-3): in fp16 storage they would sit in or below the
+// subnormal range (6e-5).  The backward schedule is linear in the gradient, so the fp16 mode carries it multiplied by 2^10
+// from the head (gscale) to the last kernel (in_conv_bw), which divides it out again in fp32.  bf16 / fp32 have the range.
+float grad_scale(int precision) { return precision == VQVS_PREC_F16 ? 1024.0f : 1.0f; }
 
 int gn_groups(int ch) {  // unet.py:345-349
   int g = 32;
@@ -1106,7 +1150,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
           a.bias = reinterpret_cast<const float*>(bp->wp(hb));
           a.logits = r.out;
           a.targets = r.backward ? r.labels : nullptr;
-          a.gscale = r.gscale;
+          a.gscale = r.gscale * grad_scale(prec);
           a.dO = bp->act(dO.off);
           a.Cb = OC;
           a.D = D;
@@ -1118,11 +1162,13 @@ int build_model(vqvs_model* m, const float* const* hp) {
         m->cur_phase = 1;
         // out.1 (3-tap conv base -> bottleneck over gelu(GN(h))) backwards: conv^T, gelu', GroupNorm backward
         TensorH t = b.new_tensor(base, 0, false, false);
-        b.add_conv_t(dO, b.P(px + "out.1.weight"), OC, base, 3, 1, t);
-        b.release(dO);
         const size_t po = b.alloc_stats(base, 0);
-        b.add_bw_act(t, BW_SAME, h, ss, t, po);
-        const size_t cfo = b.add_gn_bw(base, 0, po, ss, mr_out);
+        const bool fuse = Builder::bw_fuse_enabled();
+        const Builder::BwFuse fo{{h}, ss, base, po};
+        const int tro = b.add_conv_t(dO, b.P(px + "out.1.weight"), OC, base, 3, 1, t, fuse ? &fo : nullptr);
+        b.release(dO);
+        if (!fuse) b.add_bw_act(t, BW_SAME, h, ss, t, po);
+        const size_t cfo = b.add_gn_bw(base, 0, po, ss, mr_out, fuse ? tro : STAT_TILE);
         b.add_bw_affine(t, h, cfo, nullptr, BW_SAME, nullptr, t);
         // blocks in reverse; gradients of skip-stack tensors wait in `pending` until the down path reaches their producer
         std::map<int, TensorH> pending;
@@ -1151,6 +1197,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
           a.out = r.grad_out;
           a.C = base;
           a.T = r.Lbase;
+          a.out_scale = 1.0f / grad_scale(prec);
           return launch_in_conv_bw(a, r.B, prec, r.st);
         });
         m->cur_phase = 0;
@@ -1286,7 +1333,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
       a.bl = reinterpret_cast<const float*>(bp->wp(bl_off));
       a.logits = r.out;
       a.labels = r.backward ? r.labels : nullptr;
-      a.gscale = r.gscale;
+      a.gscale = r.gscale * grad_scale(prec);
       a.dh = bp->act(dh.off);
       return launch_cls_head(a, r.B, prec, r.st);
     });
@@ -1304,6 +1351,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
         a.out = r.grad_out;
         a.C = base;
         a.T = r.Lbase;
+        a.out_scale = 1.0f / grad_scale(prec);
         return launch_in_conv_bw(a, r.B, prec, r.st);
       });
     }
