@@ -39,7 +39,7 @@ int main(int argc, char** argv) {
   cfg.base_channels = argc > 2 ? atoi(argv[2]) : 64;
   cfg.in_channels = 1;
   cfg.out_channels = 1;
-  cfg.precision = VQVS_PREC_BF16;
+  cfg.precision = VQVS_PREC_F16;
   cfg.max_batch = 1;
   cfg.max_T = 256;
   const int n = count(&cfg);

@@ -4,7 +4,7 @@
 //
 //   g++ -O2 -std=c++17 -D__HIP_PLATFORM_AMD__ -Iinclude -I/opt/rocm/include examples/sample_unet.cpp
 //       -Lvq_voice_swap_amd -lvqvs_hip -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,$PWD/vq_voice_swap_amd -o /tmp/sample_unet
-//   /tmp/sample_unet weights.bin out.f32 [clips=2] [T=64000] [steps=50] [seed=1234] [precision: 0 fp32 | 1 bf16]
+//   /tmp/sample_unet weights.bin out.f32 [clips=2] [T=64000] [steps=50] [seed=1234] [precision: 0 fp32 | 1 bf16 | 2 fp16]
 //
 // Writes the clips as raw float32 [clips][T] (and clip 0 as 16-bit mono WAV next to it).
 #include <hip/hip_runtime_api.h>
@@ -134,7 +134,7 @@ int main(int argc, char** argv) {
   fwrite(out.data(), 4, out.size(), o);
   fclose(o);
   write_wav(std::string(argv[2]) + ".wav", out.data(), T, 16000);
-  printf("%s: %d clips x %d samples, %d steps, base_channels %d, %s\n", vqvs_version(), B, T, steps, base, precision ? "bf16" : "fp32");
+  printf("%s: %d clips x %d samples, %d steps, base_channels %d, %s\n", vqvs_version(), B, T, steps, base, precision == 0 ? "fp32" : (precision == 2 ? "fp16" : "bf16"));
   vqvs_model_destroy(model);
   return 0;
 }

@@ -169,3 +169,35 @@ def test_bench_refuses_world_size_mismatch():
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], r.stdout
     assert "refusing to report" in r.stderr
+
+
+def test_weight_snapshot_token_and_copies():
+    """The device snapshot key follows in-place parameter updates (the reference reads live parameters), and
+    modules deep-copy / pickle without a handle; index validation raises like nn.Embedding."""
+    import copy
+    import pickle
+
+    m = DiffusionModel("unet", 32)
+    p = m.predictor
+    t0 = p._weights_token()
+    assert p._weights_token() == t0
+    with torch.no_grad():
+        p.out[1].bias.add_(1.0)
+    t1 = p._weights_token()
+    assert t1 != t0
+    src = DiffusionModel("unet", 32)
+    m.load_from_pretrained(src)
+    assert p._weights_token() != t1
+    c = copy.deepcopy(m)
+    assert c.predictor._handle is None and torch.equal(c.predictor.out[1].bias, p.out[1].bias)
+    assert pickle.loads(pickle.dumps(p)).base_channels == 32
+    with pytest.raises(IndexError):
+        _native.check_index_range(torch.tensor([0, 5]), 5, "labels")
+    with pytest.raises(IndexError):
+        _native.check_index_range(torch.tensor([-1]), 5, "labels")
+    _native.check_index_range(torch.tensor([0, 4]), 5, "labels")
+    # eval-only guard: dropout in training mode is refused, not silently ignored
+    d = DiffusionModel("unet", 32, dropout=0.1)
+    d.train()
+    with pytest.raises(RuntimeError, match="dropout"):
+        d.predictor._check_inference_only(torch.zeros(1))

@@ -2,8 +2,9 @@
 // as an implicit GEMM on the gfx950 matrix cores.  See kernels.hpp for the operator contract
 // and DESIGN.md section 3 for the tiling.
 //
-//   workgroup  = 256 threads = 4 waves, output tile 256 time rows x CT channels (CT = 32*WN)
-//   wave       = 64 rows x CT channels = 2 x WN tiles of v_mfma_f32_32x32x16_bf16
+//   workgroup  = 256 threads = 4 waves (x WGN = 2 for 128-channel tiles), output tile 256 time rows x CT channels
+//   wave       = 64 rows x 32*WN channels = 2 x WN tiles of v_mfma_f32_32x32x16_f16 (VQVS_PREC_F16, operands = the stored
+//                fp16 values) or v_mfma_f32_32x32x16_bf16 (VQVS_PREC_BF16; VQVS_PREC_F32 through the split below)
 //   GEMM roles : A = activations (M = time), B = weights (N = output channel), so an
 //                accumulator lane owns ONE output channel.
 //   K loop     : segment -> chunk of 32 input channels -> tap -> 2 k-steps of 16.
@@ -15,10 +16,12 @@
 //                weights) are already in flight into registers; they are transformed
 //                (affine + GELU + bf16 split) and written to LDS buffer (i+1)&1 after the
 //                MFMAs.  One __syncthreads() per chunk.
-//   LDS rows are 64 B of bf16 padded to 80 B: a ds_read_b128 lane group then touches 16
+//   LDS rows are 64 B of 2-byte operands padded to 80 B: a ds_read_b128 lane group then touches 16
 //                distinct 16-byte slots (5*r mod 16 is a bijection) -> conflict free.
 //   VQVS_PREC_F32: operands are split x = hi + lo in bf16 and the product is evaluated as
 //                hi*hi + lo*hi + hi*lo with fp32 accumulation (drops only lo*lo ~ 2^-18).
+//   epilogue   : accumulators -> LDS -> whole rows: [GELU (ConvMFCCEncoder)] + identity skip | x gelu'(u) (guidance backward),
+//                tile statistics for the next GroupNorm (or its backward), one rounding to the storage type, coalesced stores.
 #include <cstdlib>
 
 #include "kernels.hpp"
@@ -697,11 +700,6 @@ int launch_p(const ConvArgs& a, int B, hipStream_t st, bool wide, bool big_halo,
 // (128-row tiles with three workgroups per CU were measured 10-25 % slower than 256-row tiles: the per-tile
 // fixed costs double while the SIMDs are already ~70 % busy.)
 int conv_tile_rows(int dmax, int /*Cout*/, int /*precision*/) { return TT_MAX - 2 * dmax; }
-
-int conv_lds_bytes(int precision, int wn) {
-  if (precision == 0) return wn == 2 ? lds_bytes<true, 2, 4>() : lds_bytes<true, 1, 4>();
-  return wn == 2 ? lds_bytes<false, 2, 4>() : lds_bytes<false, 1, 4>();
-}
 
 #ifdef VQVS_TIMING
 int conv_timing_read(unsigned long long* out16, int reset) {

@@ -1,7 +1,7 @@
 // Kernel argument blocks + host launchers (definitions in *.hip).
 //
 // Activation layout inside the library is channels-last: [clip][time][channel]
-// ("NTC"), element type T = float (VQVS_PREC_F32) or bf16 (VQVS_PREC_BF16).  A time
+// ("NTC"), element type T = float (VQVS_PREC_F32), fp16 (VQVS_PREC_F16) or bf16 (VQVS_PREC_BF16).  A time
 // row of C channels is contiguous, which is what an MFMA operand fragment wants
 // (8 consecutive k = 8 consecutive channels = one 16-byte LDS read) and what makes
 // every HBM access of a wave a run of whole rows.
@@ -79,7 +79,6 @@ struct ConvArgs {
 };
 
 int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st);
-int conv_lds_bytes(int precision, int wn);
 int conv_tile_rows(int dmax, int Cout, int precision);
 
 // ----------------------------------------------------------------------------------
