@@ -142,7 +142,8 @@ def main():
             torch.distributed.destroy_process_group()
         return
     n_gpus = world
-    dev = torch.device("cuda", local_rank)
+    # (gloo runs are launch-path tests: their ranks may share a GPU; RCCL runs are one rank per GPU)
+    dev = torch.device("cuda", local_rank if backend == "nccl" else local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
 
     from vq_voice_swap_amd import DiffusionModel, randn_clips
@@ -190,7 +191,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if use_dist:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
     if rank == 0:

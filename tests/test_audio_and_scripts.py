@@ -136,3 +136,26 @@ def test_cpp_host_samples_like_python(tmp_path):
     want = model.diffusion.ddpm_sample(x_T, model.predictor, steps, constrain=True, seed=seed).cpu()
     assert (got - want).abs().max().item() < 1e-4
     assert os.path.getsize(ofile + ".wav") == 44 + 2 * T
+
+
+@pytest.mark.gpu
+def test_bench_distributed_branch_two_ranks_on_one_gpu():
+    """bench.py's own multi-rank path end to end on the GPU box: `--gpus 2` starts two ranks (here over gloo, both on the one
+    GPU), each samples its shard of the clips, rank 0 gathers, the timing is the maximum over ranks, and the line says
+    n_gpus = 2.  (With RCCL the same code runs one rank per GPU; two ranks cannot share a device there.)"""
+    import json
+    import subprocess
+    import sys
+
+    env = dict(os.environ, VQVS_BENCH_BACKEND="gloo", OMP_NUM_THREADS="4")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--model", "unet32", "--batch", "3", "--sample-steps", "2",
+                        "--steps", "2", "--warmup", "1", "--T", "4096", "--no-cpu-baseline", "--no-other-modes"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 6 and out["steps"] == 2 and out["value"] > 0
+    assert out["dtype"] == "fp16" and out["scaling"] == "weak" and out["roofline"]["frac"] > 0

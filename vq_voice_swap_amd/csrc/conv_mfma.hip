@@ -138,7 +138,9 @@ struct IterGeom {
 // ds_write.  A wave-wide DMA writes 64 x 16 B contiguously, so the LDS rows are unpadded (64 B); bank conflicts of the
 // fragment reads are avoided by an XOR swizzle of the 16-byte column with bits 2..3 of the row, applied on the global
 // address side when loading and on the LDS address side when reading.
-template <typename T, bool X3, int WN, int HALO, bool SKIPV, int WGN, int WM, bool DMA>
+// BWF: the epilogue can multiply by gelu'(u) (fused GELU backward of the guidance schedule).  A template flag, not a run-time
+// branch: carried by every forward convolution the extra epilogue code measured +1.5...2 % (21.5 -> 21.9 ms per forward).
+template <typename T, bool X3, int WN, int HALO, bool SKIPV, int WGN, int WM, bool DMA, bool BWF>
 __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs a) {
   constexpr int TT = 4 * WM * 32;  // staged rows: 4 waves along time x WM MFMA tiles of 32 rows
   constexpr int NTH = 256 * WGN;  // 4 waves along time x WGN waves along output channels
@@ -540,7 +542,7 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
   f32x8 bsc = f32x8_zero(), bsh = f32x8_zero();
   const T* bxf = nullptr;
   int bxf_C = 0;
-  if (a.nbw) {
+  if ((BWF && a.nbw)) {
     const int k = (a.nbw == 2 && cg >= a.bw[1].c_begin) ? 1 : 0;
     bxf_C = a.bw[k].C;
     bxf = reinterpret_cast<const T*>(a.bw[k].xf) + (size_t)b * a.Lout * bxf_C + (cg - a.bw[k].c_begin);
@@ -576,7 +578,7 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
           v += Elem<T>::load8(skip_b + (size_t)(a.skip_resize == RESIZE_UP2 ? (tm >> 1) : tm) * a.skip_C);
         }
       }
-      if (a.nbw) {  // v <- v * gelu'(u); statistics (sum v, sum v*u)
+      if ((BWF && a.nbw)) {  // v <- v * gelu'(u); statistics (sum v, sum v*u)
         const f32x8 x = Elem<T>::load8(bxf + (size_t)tm * bxf_C);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -651,20 +653,30 @@ constexpr int lds_bytes() {
   return stage > ost ? stage : ost;
 }
 
-template <typename T, bool X3, int WN, int HALO, bool SKIPV, int WGN = 1, int WM = 2, bool DMA = false>
-int launch_t(const ConvArgs& a, int B, hipStream_t st) {
+template <typename T, bool X3, int WN, int HALO, bool SKIPV, int WGN, int WM, bool DMA, bool BWF>
+int launch_o(const ConvArgs& a, int B, hipStream_t st) {
   constexpr int LDS = lds_bytes<X3, WN, HALO, WGN, WM>();
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool attr_done = false;
   if (!attr_done) {
-    VQVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<T, X3, WN, HALO, SKIPV, WGN, WM, DMA>),
+    VQVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<T, X3, WN, HALO, SKIPV, WGN, WM, DMA, BWF>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_done = true;
   }
   dim3 grid((a.Lout + a.tile_rows - 1) / a.tile_rows, a.Cout / (WGN * WN * 32), B);
-  hipLaunchKernelGGL((conv_mfma_kernel<T, X3, WN, HALO, SKIPV, WGN, WM, DMA>), grid, dim3(256 * WGN), LDS, st, a);
+  hipLaunchKernelGGL((conv_mfma_kernel<T, X3, WN, HALO, SKIPV, WGN, WM, DMA, BWF>), grid, dim3(256 * WGN), LDS, st, a);
   VQVS_HIP(hipGetLastError());
   return 0;
+}
+
+template <typename T, bool X3, int WN, int HALO, bool SKIPV, int WGN = 1, int WM = 2, bool DMA = false>
+int launch_t(const ConvArgs& a, int B, hipStream_t st) {
+  if constexpr (!SKIPV) {  // (transposed convolutions have no identity skip)
+    if (a.nbw) return launch_o<T, X3, WN, HALO, SKIPV, WGN, WM, DMA, true>(a, B, st);
+  } else {
+    if (a.nbw) VQVS_FAIL(-1, "conv: the fused GELU backward is not built for identity-skip launches");
+  }
+  return launch_o<T, X3, WN, HALO, SKIPV, WGN, WM, DMA, false>(a, B, st);
 }
 
 template <typename T, bool X3>

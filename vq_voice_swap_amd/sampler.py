@@ -47,6 +47,13 @@ def gather_clips(local: torch.Tensor, n_total: int, T: int) -> Optional[torch.Te
     pad = pad.contiguous()
     # all_gather is the one collective every backend (RCCL, gloo) implements for equal-sized device tensors; the
     # payload (16 MB per rank at 64 clips) is negligible next to the sampling time, so rank 0 simply keeps its copy
+    if pad.is_cuda and dist.get_backend() == "gloo":  # gloo gathers host tensors only (test runs; production is RCCL)
+        host = pad.cpu()
+        bufs = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(bufs, host)
+        if rank != 0:
+            return None
+        return torch.cat([bufs[r][: e - b] for r, (b, e) in enumerate(sizes)], dim=0).to(pad.device)
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad)
     if rank != 0:
