@@ -1,5 +1,5 @@
 """Randomised ResBlock parity sweep (HIP vs oracle): random channel counts, lengths (incl. tile-boundary cases),
-dilations, resizes, FiLM on/off, batch sizes, both precisions.  Developer tool; tests/ hold the fixed cases."""
+dilations, resizes, FiLM on/off, batch sizes, all three precision modes.  Developer tool; tests/ hold the fixed cases."""
 import os, random, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -12,7 +12,7 @@ from util import rel_rms, seeded
 dev = torch.device("cuda:0")
 rng = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-worst = {"fp32": 0.0, "bf16": 0.0}
+worst = {"fp32": 0.0, "fp16": 0.0, "bf16": 0.0}
 bad = 0
 for i in range(N):
     cin = rng.choice([32, 64, 96, 128, 192, 256, 384, 512])
@@ -28,7 +28,7 @@ for i in range(N):
     e = seeded((B, emb), 6000 + i) if emb else None
     sd = {"b." + k: v.detach() for k, v in m.block.state_dict().items()}
     want = ref_cpu.res_block(x, sd, "b", dict(cin=cin, cout=cout, scale=scale, dil=dil), e)
-    for prec, tol in (("fp32", 2e-4), ("bf16", 3e-2)):
+    for prec, tol in (("fp32", 2e-4), ("fp16", 4e-3), ("bf16", 3e-2)):
         m.set_precision(prec)
         got = m(x.to(dev), None if e is None else e.to(dev)).cpu()
         err = rel_rms(got, want) if got.shape == want.shape else float("inf")
