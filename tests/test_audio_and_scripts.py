@@ -100,6 +100,27 @@ def test_sample_scripts_end_to_end(tmp_path):
     b = r.read(64000)
     r.close()
     assert b.shape == (64000,) and np.isfinite(b).all()
+    # unconditional-guidance decode (reference sample_vqvae_uncond.py) and the MFCC-encoder VQ-VAE through the same scripts
+    import sample_vqvae_uncond
+
+    dst2 = str(tmp_path / "guided.wav")
+    sample_vqvae_uncond.main(["--label", "1", "--input-file", src, "--sample-steps", "3", "--guide-vq-scale", "1.5", "--guide-label-scale",
+                              "0.7", "--schedule", "lambda t: t**2", "--seed", "9", "--precision", "fp16", ckv, dst2])
+    r = ChunkReader(dst2, 16000)
+    c = r.read(64000)
+    r.close()
+    assert c.shape == (64000,) and np.isfinite(c).all() and np.abs(c - b).max() > 1e-3
+    vm = VQVAE(base_channels=32, enc_name="conv-mfcc-ulaw", pred_name="unet", num_labels=3)
+    det_init_((k, t) for k, t in vm.state_dict().items() if ".mfcc." not in k)
+    ckm = str(tmp_path / "vm.pt")
+    vm.save(ckm)
+    assert VQVAE.load(ckm).enc_name == "conv-mfcc-ulaw"
+    dst3 = str(tmp_path / "converted_mfcc.wav")
+    sample_vqvae.main(["--label", "0", "--input-file", src, "--sample-steps", "3", "--encoding", "ulaw", "--seed", "9", "--precision", "fp16", ckm, dst3])
+    r = ChunkReader(dst3, 16000, encoding="ulaw")
+    d = r.read(64000)
+    r.close()
+    assert d.shape == (64000,) and np.isfinite(d).all()
 
 
 @pytest.mark.gpu
