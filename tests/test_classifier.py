@@ -135,3 +135,34 @@ def test_guided_sampling_with_time_remap_and_sigma_large():
     got = model.diffusion.ddpm_sample(x_T.to(dev), model.predictor, 3, sigma_large=True, constrain=True, schedule=tmap,
                                       cond_fn=clf.guidance_fn(labels.to(dev), 50.0), noise=[n.to(dev) for n in noises]).cpu()
     assert rms(got - want) < 1e-3
+
+
+@pytest.mark.gpu
+def test_guided_sampling_ten_steps_in_both_gate_modes():
+    """BASELINE config 5's path (classifier gradient at every step) held to the waveform gate in the benchmarked fp16 mode
+    too: unet32 + classifier32, 10 steps, constrained; predictor AND classifier in the mode under test."""
+    dev = torch.device("cuda:0")
+    model = DiffusionModel("unet", 32)
+    det_init_(model.state_dict().items())
+    model.eval()
+    clf = make_classifier()
+    sd_m = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    sd_c = {k: v.detach().clone() for k, v in clf.state_dict().items()}
+    labels = torch.tensor([3, 5])
+    scale, steps = 200.0, 10
+    x_T = seeded((2, 1, 8192), 171)
+    gen = torch.Generator().manual_seed(172)
+    noises = [torch.randn(x_T.shape, generator=gen) for _ in range(steps)]
+    want = ref_cpu.ddpm_sample("exp", x_T, lambda a, b: ref_cpu.unet_predictor(sd_m, 32, a, b), steps, noises, constrain=True,
+                               cond_fn=ref_cpu.classifier_cond_fn(sd_c, 32, labels, scale))
+    plain = ref_cpu.ddpm_sample("exp", x_T, lambda a, b: ref_cpu.unet_predictor(sd_m, 32, a, b), steps, noises, constrain=True)
+    clf.to(dev)
+    errs = {}
+    for prec in ("fp32", "fp16"):
+        model.set_precision(prec)
+        clf.set_precision(prec)
+        got = model.diffusion.ddpm_sample(x_T.to(dev), model.predictor, steps, constrain=True, cond_fn=clf.guidance_fn(labels.to(dev), scale),
+                                          noise=[n.to(dev) for n in noises]).cpu()
+        errs[prec] = rms(got - want)
+        assert errs[prec] < 1e-3, errs
+    assert rms(want - plain) > 5 * max(errs.values()), ("guidance term too small for the comparison to mean anything", errs, rms(want - plain))
