@@ -25,7 +25,7 @@ def read(reset=True):
     return [int(v) for v in buf]
 
 
-def run(cin, cout, Lx, B, prec="bf16", dil=2, emb=256):
+def run(cin, cout, Lx, B, prec="fp16", dil=2, emb=256):
     m = ResBlockModule(cin, emb, cout, 1.0, dil)
     det_init_(m.state_dict().items())
     m.set_precision(prec)
