@@ -332,7 +332,28 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
         sc[2 * j] = rss[j][0]; sh[2 * j] = rss[j][1]; sc[2 * j + 1] = rss[j][2]; sh[2 * j + 1] = rss[j][3];
       }
     }
-    if (!g.avg) {
+    if (!g.avg && g.nrows >= TT && (g.xform || !X3)) {
+      // fast path (the usual 3-tap segment): every staged item is a row of this segment and the whole wave takes the same
+      // branch, so the four items run as straight-line code -- no per-item exec masks, one uniform branch instead of four
+      // (measured -0.7 % convolution time)
+      if (g.xform) {
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) put_row<X3, V8>(act_hi, act_lo, act_lds[i], affine_gelu<GQ>(ra[i].get(), sc, sh));
+      } else {
+        if constexpr (!X3) {
+#pragma unroll
+          for (int i = 0; i < NPF; ++i) *reinterpret_cast<u32x4*>(act_hi + act_lds[i]) = ra[i].a;
+        }
+      }
+      if (g.base_time < 0 || g.base_time + g.nrows > g.row_bound) {
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+          const int r = (tid >> 2) + (NTH / 4) * i;
+          const int tm = g.base_time + r;
+          if (tm < 0 || tm >= g.row_bound) put_row<X3, V8>(act_hi, act_lo, act_lds[i], f32x8_zero());
+        }
+      }
+    } else if (!g.avg) {
 #pragma unroll
       for (int i = 0; i < NPF; ++i) {
         const int r = (tid >> 2) + (NTH / 4) * i;
