@@ -61,8 +61,10 @@ def cpu_baseline(base: int, T: int, sample_steps: int):
     from vq_voice_swap_amd.det_init import det_tensor
     from vq_voice_swap_amd import _native
 
-    # torch's CPU convolutions stop scaling (and then collapse) far below the 256 hardware threads of the
-    # GPU box: use at most 32 threads and say so in "cores".
+    # torch's CPU convolutions stop scaling (and then collapse) far below the 256 hardware threads of the GPU box
+    # (tools/cpu_baseline_scaling.py, unet64 forward of 4 clips: 16 threads 0.030 clips/s, 32: 0.027, 64: 0.018, 128: 0.009),
+    # and 8 processes x 32 threads side by side are slower still in aggregate (0.010 clips/s: the host is memory-bound):
+    # use at most 32 threads of ONE process and say so in "cores".
     cores = min(32, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     cfg = _native.Cfg()
