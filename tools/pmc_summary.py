@@ -4,7 +4,7 @@ import csv, glob, os, sys, collections
 
 def short(name):
     n = name
-    for key in ("conv_mfma_kernel", "gn_prepare_kernel", "in_conv_kernel", "out_conv_kernel", "film_kernel", "time_embed_kernel",
+    for key in ("conv_ws_kernel", "conv_mfma_kernel", "gn_prepare_kernel", "in_conv_kernel", "out_conv_kernel", "film_kernel", "time_embed_kernel",
                 "ddpm_step_kernel", "ddpm_x0sum_kernel", "randn_kernel"):
         if key in n:
             tail = ""

@@ -394,4 +394,6 @@ int vqvs_profile_read(vqvs_model* m, float* h_ms, int cap) {
 #ifdef VQVS_TIMING
 namespace vqvs { int conv_timing_read(unsigned long long* out16, int reset); }
 extern "C" int vqvs_debug_conv_timing(unsigned long long* h_out16, int reset) { return vqvs::conv_timing_read(h_out16, reset); }
+namespace vqvs { int ws_timing_read(unsigned long long* out32, int reset); }
+extern "C" int vqvs_debug_ws_timing(unsigned long long* h_out32, int reset) { return vqvs::ws_timing_read(h_out32, reset); }
 #endif

@@ -1,0 +1,799 @@
+// Wave-specialised, persistent form of the fused convolution (kernels.hpp ConvArgs) for the 2-byte
+// storage modes.  Same operator contract and the same GEMM roles as conv_mfma.hip -- A = activations (M = time), B = weights
+// (N = output channel), K = (segment, chunk of 32 input channels, tap) -- but the work of a tile is split between two kinds of
+// waves that never change role, so the SIMD's matrix pipe and its vector ALU are busy at the same time instead of in turns:
+//
+//   workgroup = 16 waves = one per CU (LDS-bound), persistent: it walks a contiguous run of (clip, time tile, channel tile)s.
+//   waves 8..15  PRODUCERS: global loads of the raw activation rows (three chunks in flight in registers), the fused prologue
+//                (GroupNorm/FiLM affine + GELU, reference unet.py:280-285, 311-315) as scalar fp32 VALU, ds_write of MFMA operands.
+//   waves 0..7   CONSUMERS: weight chunks by LDS-DMA (buffer_load ... lds, no registers), ds_read fragments, MFMAs; at the
+//                end of a tile the statistics of the next GroupNorm and ONE rounding to the storage type into an LDS out-tile,
+//                which they store as whole rows at the beginning of the next step.
+//   One s_barrier per K chunk ("step"): during step g the consumers multiply chunk g (stage g & 1) while the producers stage
+//   chunk g + 1 (stage (g + 1) & 1) -- across tile boundaries too, so there is no per-tile pipeline fill.
+//   The identity skip (unet.py:316) is one more K segment whose B operand is the identity matrix: x * 1.0 accumulates exactly in
+//   fp32, so the accumulator holds bias + conv + skip before its only rounding, and the epilogue needs no row-layout pass.
+//
+// LDS rows are 64 B (32 channels) with the 16-byte column XOR-swizzled by bits 2..3 of the row, for activations (written by
+// ds_write_b128) and weights (lane-linear DMA image, swizzle applied to the source address) alike: ds_read_b128 conflict-free.
+#include <cstdlib>
+
+#include "kernels.hpp"
+
+namespace vqvs {
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+template <typename T> struct WsOp;
+template <> struct WsOp<half_t> {
+  typedef f16x8 v8;
+  static constexpr unsigned short one = 0x3C00;
+  static constexpr int gq = GELU_POLY7;
+};
+template <> struct WsOp<bf16_t> {
+  typedef bf16x8 v8;
+  static constexpr unsigned short one = 0x3F80;
+  static constexpr int gq = GELU_POLY6;
+};
+__device__ __forceinline__ f32x16 ws_mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 ws_mfma(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+
+// The prologue arithmetic is written on scalars on purpose: a packed fp32 instruction (v_pk_fma_f32) does not run beside
+// another wave's MFMAs on the same SIMD, a plain one does (profiles/r02_ubench_role_split.txt).
+template <int Q>
+__device__ __forceinline__ float ws_gelu(float v) {
+  const float vc = __builtin_amdgcn_fmed3f(v, -4.0f, 4.0f);
+  const float w = vc * vc;
+  float p;
+  if constexpr (Q == GELU_POLY6) {
+    p = fmaf(2.81608722e-08f, w, -1.89188380e-06f);
+    p = fmaf(p, w, 5.41903041e-05f);
+    p = fmaf(p, w, -8.78980255e-04f);
+    p = fmaf(p, w, 9.11294959e-03f);
+    p = fmaf(p, w, -6.53883549e-02f);
+    p = fmaf(p, w, 3.98526915e-01f);
+  } else {
+    p = fmaf(-1.301278171e-09f, w, 1.041951057e-07f);
+    p = fmaf(p, w, -3.657111166e-06f);
+    p = fmaf(p, w, 7.485478930e-05f);
+    p = fmaf(p, w, -1.006488756e-03f);
+    p = fmaf(p, w, 9.505392772e-03f);
+    p = fmaf(p, w, -6.588783436e-02f);
+    p = fmaf(p, w, 3.986733897e-01f);
+  }
+  return v * fmaf(vc, p, 0.5f);
+}
+
+// A K segment of the launch (kernels.hpp SegDesc, plus the identity-skip pseudo-segment), as the kernel wants it.  The waves keep
+// the segment they are in -- and, prefetched, the one that follows -- in scalar registers; the per-chunk quantities are those
+// plus a multiple of the chunk index, so a step costs a handful of scalar adds and no argument loads.
+struct WsSeg {
+  const void* src;   // [B][Lout][Csrc] of T
+  const float2* ss;  // (scale, shift) rows [B][ss_stride], or nullptr = raw (no prologue)
+  int Csrc;
+  int c0;            // first source channel (identity segment: relative to the output channel tile)
+  int nch;           // chunks of 32 channels
+  int ntaps;         // 3, 1, or 0 = identity segment (weights = the identity block, written by the producers)
+  int dil;           // dilation of a 3-tap segment, else 0: LDS row 0 holds time t0 - dil
+  int ss_stride, ss_c0;
+  int ss_lds;        // byte offset of this segment's (scale, shift) pairs in the per-clip LDS table
+  int wbase, wstep;  // byte offset of chunk 0's packed weights [tap][Cout][32], bytes per chunk
+  int lds_off;       // resident-weights form: byte offset of chunk 0's image in the resident block
+};
+struct WsArgs {
+  WsSeg seg[4];
+  int nseg, nchunks;  // segments (incl. the identity one), chunks per tile (>= 2)
+  const void* w;
+  int w_bytes;
+  const float* bias;
+  void* out;
+  float* stats;
+  int Cout, Lout, TTO, ntx, nty, ntiles, ntiles_stat;
+  int wres_bytes;  // resident-weights form: bytes of all segments' weights
+  int ss_bytes;    // bytes of one clip's (scale, shift) table (all prologue segments), ss_ring copies of it live in LDS
+  int ss_ring;     // 2 or 4 (power of two): clips whose chunks can be in flight at once
+};
+#define WS_SEGF(s, f) ((s) == 0 ? a.seg[0].f : ((s) == 1 ? a.seg[1].f : ((s) == 2 ? a.seg[2].f : a.seg[3].f)))
+
+struct TileCo {
+  int b, tx, ty;
+};
+
+#ifndef VQVS_WS_EXP
+#define VQVS_WS_EXP 0  // ablation bits for tools/experiments (results are WRONG when non-zero): 1 no activation loads, 2 no weight DMA,
+#endif                // 4 no tile store, 8 no prologue arithmetic, 16 no MFMA loop, 32 no tile-end statistics / rounding
+
+#ifdef VQVS_TIMING
+__device__ unsigned long long g_ws_timing[32];
+#define WS_TMARK(i)                                                \
+  {                                                                \
+    const unsigned long long _t = __builtin_amdgcn_s_memtime();    \
+    tacc[i] += _t - tlast;                                         \
+    tlast = _t;                                                    \
+  }
+#else
+#define WS_TMARK(i)
+#endif
+
+// RES: the launch's weights fit into LDS next to everything else (one output channel tile per launch, K small): they are fetched
+// once per workgroup instead of once per tile and step -- the per-CU path from L2 is the scarce resource (~11 B / cycle / CU,
+// whether the bytes come from HBM or from L2), and a re-streamed 32-channel weight chunk (3 * CT * 64 B) weighs more on it than
+// the activation chunk it multiplies (16 KiB).
+template <typename T, int WN, bool RES>
+__global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
+  constexpr int CT = 64 * WN;             // output channels per tile: 2 consumer columns x WN MFMA tiles of 32
+  constexpr int ACT_BYTES = 256 * 64;     // 256 staged rows x 32 channels
+  constexpr int W_BYTES = 3 * CT * 64;
+  constexpr int STAGE = ACT_BYTES + W_BYTES;
+  constexpr int OP = CT * 4 + 16;         // out-tile pitch in bytes: one LDS row = one PAIR of output rows, a dword per channel (lo = even row)
+  // streaming form: [stage 0: activations | weights][stage 1][out-tile][statistics]
+  // resident form : [activations 0][activations 1][identity block 0][identity block 1][out-tile][statistics][all weights]
+  constexpr int ACT_STRIDE = RES ? ACT_BYTES : STAGE;      // activation slot s at s * ACT_STRIDE
+  constexpr int WS_OFF = RES ? 2 * ACT_BYTES : ACT_BYTES;  // streamed (or identity) weight slot s at WS_OFF + s * WS_STRIDE
+  constexpr int WS_STRIDE = RES ? CT * 64 : STAGE;
+  constexpr int O_OFF = RES ? 2 * ACT_BYTES + 2 * CT * 64 : 2 * STAGE;
+  constexpr int R_OFF = O_OFF + 128 * OP;  // [4 time quarters][CT][2] partial statistics
+  constexpr int WRES_OFF = R_OFF + 4 * CT * 8;
+  const int SS_OFF = WRES_OFF + (RES ? a.wres_bytes : 0);  // per-clip (scale, shift) tables, a.ss_ring of them
+  constexpr int GQ = WsOp<T>::gq;
+  typedef typename WsOp<T>::v8 V8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef VQVS_TIMING
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = __builtin_amdgcn_s_memtime();
+#endif
+
+  // Tile range of this workgroup.  Workgroup w runs on XCD w % 8 (observed, used for speed only): every XCD gets one contiguous
+  // run of tiles (channel tile fastest, then time, then clip), every workgroup a contiguous piece of it -- halo rows and the
+  // input rows shared by channel tiles are re-read through the same L2.
+  int tb, te;
+  {
+    const int nwg = (int)gridDim.x, w = (int)blockIdx.x;
+    const int nx = nwg < 8 ? nwg : 8;
+    const int k = w % nx, i = w / nx;
+    const int nk = (nwg - k + nx - 1) / nx;
+    const unsigned tot = (unsigned)a.ntiles;  // (host side: ntiles < 2^24, so the products below fit 32 bits)
+    const unsigned s = tot * (unsigned)k / (unsigned)nx, e = tot * (unsigned)(k + 1) / (unsigned)nx;
+    const unsigned len = e - s;
+    tb = (int)(s + len * (unsigned)i / (unsigned)nk);
+    te = (int)(s + len * (unsigned)(i + 1) / (unsigned)nk);
+  }
+  const int n = a.nchunks;
+  const int Q = (te - tb) * n;  // steps of this workgroup
+  if (Q <= 0) return;
+  TileCo first;
+  {
+    const int rest = tb / a.nty;
+    first.ty = tb - rest * a.nty;
+    first.b = rest / a.ntx;
+    first.tx = rest - first.b * a.ntx;
+  }
+  auto next_tile = [&](TileCo& t) {
+    if (++t.ty == a.nty) {
+      t.ty = 0;
+      if (++t.tx == a.ntx) {
+        t.tx = 0;
+        ++t.b;
+      }
+    }
+  };
+  auto sync_lds = [&]() {  // LDS writes / reads of this wave are done; global loads stay in flight across the barrier
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  if (wave >= 8) {
+    // =============================== producers ===============================
+    const int pt = tid - 512;
+    const int oct = pt & 3, r0 = pt >> 2;  // this thread stages rows r0 and r0 + 128, channel octet `oct`, of every chunk
+    const int dst0 = r0 * 64 + ((oct ^ ((r0 >> 2) & 3)) << 4);
+    struct Raw {
+      u32x4 a0, a1;
+      unsigned meta;  // bit 0: prologue, bit 1 / 2: row 0 / 1 inside the clip (outside: the convolution's zero padding),
+                      // bit 3: identity segment, bits 8..: its chunk index
+      int ssaddr;     // LDS byte address of this thread's eight (scale, shift) pairs
+    };
+    Raw R0, R1, R2;
+    struct Prep {  // everything the two loads of a chunk need
+      i32x4 rs;
+      int off0, off1, ssaddr;
+      unsigned meta;
+    };
+    // load cursor: tile `lt`, segment `lseg`, chunk `lch` of the next loads; `cur` = their parameters (updated incrementally inside
+    // a segment, rebuilt from `nx` = the prefetched fields of the segment that follows when one is entered)
+    TileCo lt = first;
+    int lseg = 0, lch = 0, lnch = 0, issued = 0;
+    struct SegF {
+      const void* src;
+      const float2* ss;
+      int Csrc, c0, nch, ntaps, dil, ss_stride, ss_c0, ss_lds;
+    };
+    auto fetch = [&](int sg) -> SegF {
+      return SegF{WS_SEGF(sg, src), WS_SEGF(sg, ss), WS_SEGF(sg, Csrc), WS_SEGF(sg, c0), WS_SEGF(sg, nch),
+                  WS_SEGF(sg, ntaps), WS_SEGF(sg, dil), WS_SEGF(sg, ss_stride), WS_SEGF(sg, ss_c0), WS_SEGF(sg, ss_lds)};
+    };
+    SegF nx = fetch(0);
+    Prep cur;
+    int cur_xf = 0, cur_id = 0, cur_idch = 0;  // (wave-uniform parts of meta, kept scalar)
+    int ss_clip = -1;  // clip whose (scale, shift) table was written last
+    unsigned cur_valid = 0;
+    auto enter = [&]() {  // the cursor has just moved to (lt, lseg, chunk 0)
+      const SegF f = nx;
+      const int L = a.Lout;
+      const unsigned long long clip = reinterpret_cast<unsigned long long>(f.src) + (unsigned long long)((unsigned)lt.b * (unsigned)L) * (unsigned)(f.Csrc * 2);
+      // raw buffer descriptor of this clip's rows: out-of-range rows (before / after the clip) read as zero
+      cur.rs[0] = (int)(unsigned)clip;
+      cur.rs[1] = (int)((unsigned)(clip >> 32) & 0xffffu);
+      cur.rs[2] = L * f.Csrc * 2;
+      cur.rs[3] = 0x00020000;
+      const int tm0 = lt.tx * a.TTO - f.dil + r0, tm1 = tm0 + 128;  // time of this thread's two rows
+      cur.off0 = (tm0 * f.Csrc + f.c0 + (f.ntaps == 0 ? lt.ty * CT : 0) + oct * 8) * 2;
+      cur.off1 = cur.off0 + 256 * f.Csrc;
+      if (lseg == 0 && lt.b != ss_clip) {
+        // first chunk of a new clip: its (scale, shift) rows (every prologue segment's) go to LDS once -- the producers then read
+        // them with ds_read instead of four more global loads per chunk and thread.  Slot b % ring: chunks of at most `ring`
+        // clips are in flight (host: ring = 4 when a clip can take fewer than four steps).
+        ss_clip = lt.b;
+        const int nb = a.ss_bytes;
+        if (pt * 16 < nb) {
+          // which segment does byte pt * 16 of the table belong to?
+          int sg = 0;
+#pragma unroll
+          for (int k = 1; k < 4; ++k)
+            if (k < a.nseg && WS_SEGF(k, ss) != nullptr && pt * 16 >= WS_SEGF(k, ss_lds)) sg = k;
+          const float2* const row = WS_SEGF(sg, ss) + (size_t)((unsigned)lt.b * (unsigned)WS_SEGF(sg, ss_stride) + (unsigned)WS_SEGF(sg, ss_c0));
+          const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(row) + (pt * 16 - WS_SEGF(sg, ss_lds)));
+          *reinterpret_cast<f32x4*>(smem + SS_OFF + (lt.b & (a.ss_ring - 1)) * nb + pt * 16) = v;
+        }
+      }
+      cur.ssaddr = SS_OFF + (lt.b & (a.ss_ring - 1)) * a.ss_bytes + f.ss_lds + oct * 64;
+      cur_xf = f.ss != nullptr ? 1 : 0;
+      cur_id = f.ntaps == 0 ? 1 : 0;
+      cur_idch = 0;
+      cur_valid = ((tm0 >= 0 && tm0 < L) ? 2u : 0u) | ((tm1 >= 0 && tm1 < L) ? 4u : 0u);
+      lnch = f.nch;
+      nx = fetch(lseg + 1 == a.nseg ? 0 : lseg + 1);
+    };
+    enter();
+    sync_lds();  // (the first clip's (scale, shift) table is visible to every producer wave; the consumers match this barrier)
+    auto prepare = [&]() -> Prep {
+      Prep pr = cur;
+      pr.meta = cur_valid | (unsigned)(cur_xf | (cur_id << 3) | (cur_idch << 8));
+      if (++issued < Q) {  // (past the end the last chunk is simply loaded again and never staged)
+        if (++lch == lnch) {
+          lch = 0;
+          if (++lseg == a.nseg) {
+            lseg = 0;
+            next_tile(lt);
+          }
+          enter();
+        } else {
+          cur.off0 += 64;
+          cur.off1 += 64;
+          cur.ssaddr += 256;
+          cur_idch += cur_id;  // identity segment: chunk index within the channel tile
+        }
+      }
+      return pr;
+    };
+    // The loads are inline assembly on purpose: hipcc's own wait insertion drains the whole queue (vmcnt(0)) at the top of the
+    // rotating loop, which would serialise every third step behind loads issued a moment earlier.  Each chunk issues exactly two
+    // loads (this thread's two activation rows), so "this chunk has landed, the two younger ones may still be in flight" is
+    // vmcnt(4), stated in acquire().
+    auto issue = [&](Raw& r, const Prep& pr) {
+      r.meta = pr.meta;
+      r.ssaddr = pr.ssaddr;
+      if (VQVS_WS_EXP & 1) {
+        asm volatile("" : "=v"(r.a0), "=v"(r.a1));  // (opaque garbage, so that nothing downstream folds away)
+        return;
+      }
+      // (the descriptor is wave-uniform by construction; say so, or the compiler may hand the assembly a VGPR copy of it when it
+      //  runs short of SGPRs.  The s_nop covers the VALU-write -> VMEM-read wait states.)
+      i32x4 rs;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rs[i] = __builtin_amdgcn_readfirstlane(pr.rs[i]);
+      asm volatile(
+          "s_nop 4\n\t"
+          "buffer_load_dwordx4 %0, %2, %4, 0 offen\n\t"
+          "buffer_load_dwordx4 %1, %3, %4, 0 offen"
+          : "=&v"(r.a0), "=&v"(r.a1)
+          : "v"(pr.off0), "v"(pr.off1), "s"(rs));
+    };
+    auto acquire = [&](Raw& r) {  // the oldest chunk in flight has landed; nothing that reads it may be scheduled above this
+      if (VQVS_WS_EXP & 1) return;
+      asm volatile("s_waitcnt vmcnt(4)" : "+v"(r.a0), "+v"(r.a1));
+    };
+    auto xform8 = [&](u32x4 raw, const f32x4& s0, const f32x4& s1, const f32x4& s2, const f32x4& s3) -> u32x4 {
+      const V8 h = __builtin_bit_cast(V8, raw);
+      V8 o;
+      o[0] = (T)ws_gelu<GQ>(fmaf((float)h[0], s0[0], s0[1]));
+      o[1] = (T)ws_gelu<GQ>(fmaf((float)h[1], s0[2], s0[3]));
+      o[2] = (T)ws_gelu<GQ>(fmaf((float)h[2], s1[0], s1[1]));
+      o[3] = (T)ws_gelu<GQ>(fmaf((float)h[3], s1[2], s1[3]));
+      o[4] = (T)ws_gelu<GQ>(fmaf((float)h[4], s2[0], s2[1]));
+      o[5] = (T)ws_gelu<GQ>(fmaf((float)h[5], s2[2], s2[3]));
+      o[6] = (T)ws_gelu<GQ>(fmaf((float)h[6], s3[0], s3[1]));
+      o[7] = (T)ws_gelu<GQ>(fmaf((float)h[7], s3[2], s3[3]));
+      return __builtin_bit_cast(u32x4, o);
+    };
+    auto stage = [&](const Raw& r, int slot) {
+      char* const sb = smem + slot * ACT_STRIDE;
+      const int um = __builtin_amdgcn_readfirstlane((int)r.meta);
+      u32x4 o0 = r.a0, o1 = r.a1;
+      if ((um & 1) && !(VQVS_WS_EXP & 8)) {
+        const f32x4* const sp = reinterpret_cast<const f32x4*>(smem + r.ssaddr);
+        const f32x4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
+        o0 = xform8(r.a0, s0, s1, s2, s3);
+        o1 = xform8(r.a1, s0, s1, s2, s3);
+      }
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      if (!(r.meta & 2u)) o0 = z;
+      if (!(r.meta & 4u)) o1 = z;
+      *reinterpret_cast<u32x4*>(sb + dst0) = o0;
+      *reinterpret_cast<u32x4*>(sb + dst0 + 128 * 64) = o1;
+      if (um & 8) {
+        // identity segment: its "weights" are the identity block for output channels [ch * 32, +32) of the tile, written here
+        // in the DMA image's layout: row j = output channel, 32 k-values (k = skip channel - ch * 32), swizzled octets
+        if (pt < CT * 4) {
+          const int j = pt >> 2;
+          const int dlt = j - (um >> 8) * 32 - oct * 8;  // element e of this octet is 1 iff e == dlt
+          u32x4 bi;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            bi[e] = (dlt == 2 * e ? (unsigned)WsOp<T>::one : 0u) | (dlt == 2 * e + 1 ? ((unsigned)WsOp<T>::one << 16) : 0u);
+          *reinterpret_cast<u32x4*>(smem + WS_OFF + slot * WS_STRIDE + j * 64 + ((oct ^ ((j >> 2) & 3)) << 4)) = bi;
+        }
+      }
+    };
+
+    {
+      const Prep p0 = prepare();
+      issue(R0, p0);
+      const Prep p1 = prepare();
+      issue(R1, p1);
+      const Prep p2 = prepare();
+      issue(R2, p2);
+    }
+    int q = 0;
+    WS_TMARK(2)
+#define WS_PBODY(R)              \
+  {                              \
+    const Prep pr = prepare();   \
+    WS_TMARK(2)                  \
+    acquire(R);                  \
+    WS_TMARK(0)                  \
+    stage(R, q & 1);             \
+    issue(R, pr);                \
+    WS_TMARK(1)                  \
+    sync_lds();                  \
+    WS_TMARK(3)                  \
+  }                              \
+  if (++q == Q) break;
+    for (;;) {
+      WS_PBODY(R0)
+      WS_PBODY(R1)
+      WS_PBODY(R2)
+    }
+#undef WS_PBODY
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the over-issued loads of the tail
+    sync_lds();  // the consumers' last step
+#ifdef VQVS_TIMING
+    if (lane == 0 && ((int)blockIdx.x & 15) == 3) {
+      for (int i = 0; i < 4; ++i) atomicAdd(&g_ws_timing[i], tacc[i]);
+      atomicAdd(&g_ws_timing[16], 1ull);
+      atomicAdd(&g_ws_timing[18], (unsigned long long)Q);
+    }
+#endif
+  } else {
+    // =============================== consumers ===============================
+    const int wt = wave & 3, wc = wave >> 2;  // time quarter (64 rows), channel half (WN x 32 channels)
+    const int l31 = lane & 31, hh = lane >> 5;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.w_bytes, 0x00020000);
+    T* const outp = reinterpret_cast<T*>(a.out);
+
+    f32x16 acc[2][WN];
+    // LDS byte offset of this lane's B (weight) fragments for k-step 0 / 1: rows tap * CT + wc * WN * 32 + nt * 32 + l31 -- the
+    // swizzle depends on l31 only, taps and channel tiles are immediate offsets
+    int boff[2];
+    {
+      const int wr = wc * (WN * 32) + l31;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) boff[ks] = wr * 64 + (((ks * 2 + hh) ^ ((wr >> 2) & 3)) << 4);
+    }
+    // weight DMA: piece p = 16 rows of 64 B; this lane's row within a piece and its (source-side) swizzled octet
+    const int dma_lane = ((lane >> 2) * 32 + (((lane & 3) ^ ((lane >> 4) & 3)) * 8)) * 2;
+
+    auto dma = [&](int ntaps, int woff, const TileCo& t, int slot) {  // weights of a chunk -> stage `slot`, 1 KiB (16 rows) per wave-instruction
+      if (RES || ntaps == 0 || (VQVS_WS_EXP & 2)) return;  // identity segment: the producers write its identity block
+      const int wb = woff + t.ty * (CT * 64);
+      const int np = ntaps * (CT / 16);
+      for (int p = wave; p < np; p += 8) {
+        const int tap = (p * 16) / CT, colb = p * 16 - tap * CT;
+        const int voff = wb + (tap * a.Cout + colb) * 64 + dma_lane;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(smem + WS_OFF + slot * WS_STRIDE + p * 1024), 16, voff, 0, 0, 0);
+      }
+    };
+    auto sync_all = [&]() {  // + this wave's weight DMA has landed
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    };
+
+    // coordinates of the tile whose out-tile sits in LDS (stored at the start of the next step)
+    TileCo pt_{0, 0, 0};
+    bool pending = false;
+    auto store_tile = [&]() {
+      int zl = 0;
+      asm volatile("" : "+v"(zl));  // (keeps the per-lane address arithmetic of this rare block out of the loop's live registers)
+      const int ltid = tid + zl;
+      const int t0 = pt_.tx * a.TTO;
+      const int nvalid = min(a.TTO, a.Lout - t0);
+      const int co0 = pt_.ty * CT;
+      if (a.stats != nullptr && ltid < CT) {
+        const float2* const red = reinterpret_cast<const float2*>(smem + R_OFF);
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {  // fixed order: deterministic
+          const float2 v = red[g * CT + ltid];
+          t1 += v.x;
+          t2 += v.y;
+        }
+        float2* o = reinterpret_cast<float2*>(a.stats) + ((size_t)pt_.b * a.ntiles_stat + pt_.tx) * a.Cout + co0 + ltid;
+        *o = float2{t1, t2};
+      }
+      // out-tile -> global: a thread takes 8 channels of a row pair (2 x 16 B of LDS), separates the two rows (lo / hi halves of
+      // the dwords) and stores 16 B of each; a wave writes whole 2 x CT-byte rows
+      constexpr int PPR = CT / 8;  // 8-channel pieces per row
+      constexpr int PSTEP = 512 / PPR;  // row pairs between this thread's pieces
+      const int p0 = ltid / PPR, col = ltid - p0 * PPR;
+      const char* const lsrc = smem + O_OFF + p0 * OP + col * 32;
+      T* const gdst = outp + ((size_t)pt_.b * a.Lout + t0 + 2 * p0) * a.Cout + co0 + col * 8;
+#pragma unroll
+      for (int i = 0; i < 128 / PSTEP; ++i) {
+        const int row = 2 * (p0 + i * PSTEP);
+        if (row < nvalid) {
+          const u32x4 lo = *reinterpret_cast<const u32x4*>(lsrc + i * PSTEP * OP);
+          const u32x4 hi = *reinterpret_cast<const u32x4*>(lsrc + i * PSTEP * OP + 16);
+          u32x4 e, o;
+          e[0] = __builtin_amdgcn_perm(lo[1], lo[0], 0x05040100u);
+          e[1] = __builtin_amdgcn_perm(lo[3], lo[2], 0x05040100u);
+          e[2] = __builtin_amdgcn_perm(hi[1], hi[0], 0x05040100u);
+          e[3] = __builtin_amdgcn_perm(hi[3], hi[2], 0x05040100u);
+          o[0] = __builtin_amdgcn_perm(lo[1], lo[0], 0x07060302u);
+          o[1] = __builtin_amdgcn_perm(lo[3], lo[2], 0x07060302u);
+          o[2] = __builtin_amdgcn_perm(hi[1], hi[0], 0x07060302u);
+          o[3] = __builtin_amdgcn_perm(hi[3], hi[2], 0x07060302u);
+          T* const g = gdst + (size_t)(2 * i * PSTEP) * a.Cout;
+          *reinterpret_cast<u32x4*>(g) = e;
+          if (row + 1 < nvalid) *reinterpret_cast<u32x4*>(g + a.Cout) = o;
+        }
+      }
+    };
+
+    // chunk cursors: `ct` / `cci` = tile and chunk of the current step; the DMA cursor (tile `nt_`, segment `dseg`, chunk `dch`) runs
+    // one chunk ahead; its segment's fields are fetched when the segment is entered, the following segment's are prefetched
+    TileCo ct = first, nt_ = first;
+    int cci = 0;
+    struct SegW {
+      int nch, ntaps, dil, wbase, wstep, lds_off;
+    };
+    auto fetchw = [&](int sg) -> SegW {
+      return SegW{WS_SEGF(sg, nch), WS_SEGF(sg, ntaps), WS_SEGF(sg, dil), WS_SEGF(sg, wbase), WS_SEGF(sg, wstep), WS_SEGF(sg, lds_off)};
+    };
+    int dseg = 0, dch = 0;
+    SegW dw = fetchw(0), dnx = fetchw(a.nseg > 1 ? 1 : 0);
+    int d_woff = dw.wbase;
+    // LDS byte offset of the weights of the chunk the DMA cursor points at, when it is consumed in a step of parity `par`
+    auto wlds = [&](int par) { return (RES && dw.ntaps != 0) ? WRES_OFF + dw.lds_off + dch * dw.wstep : WS_OFF + par * WS_STRIDE; };
+    if constexpr (RES) {
+      // all weights, once: segment images are contiguous in the packed weights ([chunk][tap][Cout][32], Cout == CT here)
+      const int nsg = a.nseg;
+      for (int sg = 0; sg < nsg; ++sg) {
+        const int np = (WS_SEGF(sg, nch) * WS_SEGF(sg, wstep)) >> 10;
+        const int gb = WS_SEGF(sg, wbase), lb = WS_SEGF(sg, lds_off);
+        for (int p = wave; p < np; p += 8)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(smem + WRES_OFF + lb + p * 1024), 16, gb + p * 1024 + dma_lane, 0, 0, 0);
+      }
+    }
+    auto dma_advance = [&]() {
+      if (++dch == dw.nch) {
+        dch = 0;
+        if (++dseg == a.nseg) {
+          dseg = 0;
+          next_tile(nt_);
+        }
+        dw = dnx;
+        d_woff = dw.wbase;
+        dnx = fetchw(dseg + 1 == a.nseg ? 0 : dseg + 1);
+      } else {
+        d_woff += dw.wstep;
+      }
+    };
+    __builtin_amdgcn_s_barrier();  // (pairs with the producers' barrier behind their first (scale, shift) table)
+    dma(dw.ntaps, d_woff, nt_, 0);
+    int ntaps = dw.ntaps, d = dw.dil, wb = wlds(0);  // current chunk
+    dma_advance();
+    float bj[WN];
+    int bias_ty = -1;
+    sync_all();
+    WS_TMARK(4)
+    for (int g = 0; g < Q; ++g) {
+      if (cci == 0) {  // first chunk of a tile
+        if (ct.ty != bias_ty) {  // (one channel tile per launch at Cout <= 128: loaded once)
+          bias_ty = ct.ty;
+#pragma unroll
+          for (int nt = 0; nt < WN; ++nt) bj[nt] = a.bias[ct.ty * CT + wc * (WN * 32) + nt * 32 + l31];
+        }
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            acc[0][nt][r] = bj[nt];
+            acc[1][nt][r] = bj[nt];
+          }
+      }
+      WS_TMARK(0)
+      const int nx_ntaps = dw.ntaps, nx_dil = dw.dil, nx_wb = wlds((g + 1) & 1);  // the chunk the DMA cursor points at = the next step's
+      if (g + 1 < Q) {
+        dma(dw.ntaps, d_woff, nt_, (g + 1) & 1);
+        dma_advance();
+      }
+      WS_TMARK(1)
+      const char* const sb = smem + (g & 1) * ACT_STRIDE;
+      const char* const sw = smem + wb;
+      int row = wt * 64 + l31;  // LDS row of output row l31 (+32) of this wave for tap 0; +d per tap
+      {
+        // (an identity-segment chunk is a 1-tap chunk whose weights are the identity block the producers wrote: rows of the other
+        //  channel tiles are zero, so every wave runs the same code on every chunk)
+        const int nk = (VQVS_WS_EXP & 16) ? 0 : (ntaps == 3 ? 3 : 1);
+        for (int k = 0; k < nk; ++k, row += d) {
+          const int swz = (row >> 2) & 3;
+          const char* const wk = sw + k * (CT * 64);
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const int ao = row * 64 + (((ks * 2 + hh) ^ swz) << 4);
+            const V8 a0 = *reinterpret_cast<const V8*>(sb + ao);
+            const V8 a1 = *reinterpret_cast<const V8*>(sb + ao + 32 * 64);
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt) {
+              const V8 bf = *reinterpret_cast<const V8*>(wk + boff[ks] + nt * 32 * 64);
+              acc[0][nt] = ws_mfma(a0, bf, acc[0][nt]);
+              acc[1][nt] = ws_mfma(a1, bf, acc[1][nt]);
+            }
+          }
+        }
+      }
+      WS_TMARK(2)
+      // last chunk of the tile: statistics + rounding + out-tile
+      if (cci == n - 1 && (VQVS_WS_EXP & 32)) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < WN; ++nt) asm volatile("" ::"v"(acc[mt][nt][0]), "v"(acc[mt][nt][15]));  // keep the MFMAs alive
+        pt_ = ct;
+        pending = true;
+      }
+      if (cci == n - 1 && !(VQVS_WS_EXP & 32)) {
+        int zl = 0;
+        asm volatile("" : "+v"(zl));
+        const int t0 = ct.tx * a.TTO;
+        const int nvalid = min(a.TTO, a.Lout - t0);
+        const int lim = nvalid - (wt * 64 + 4 * hh) + zl;  // rows of this lane: mt * 32 + (r & 3) + 8 * (r >> 2) < lim are real
+        if (wt * 64 + 64 > nvalid) {
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+              for (int r = 0; r < 16; ++r)
+                if (mt * 32 + (r & 3) + 8 * (r >> 2) >= lim) acc[mt][nt][r] = 0.f;
+        }
+        // round PAIRS of rows (same channel) into one dword of the out-tile; the statistics are those of the rounded values
+        char* const ob = smem + O_OFF + (wt * 32 + 2 * hh) * OP + (wc * (WN * 32) + l31 + zl) * 4;
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) {
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+              char* const o0 = ob + (mt * 16 + ((r & 3) >> 1) + 4 * (r >> 2)) * OP + nt * 128;
+              if constexpr (WsOp<T>::one == 0x3C00) {
+                // fp16: one v_cvt_pk per pair; sum = dot((a, b), (1, 1)), sum of squares = dot((a, b), (a, b)), fp32 accumulation
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                const h2 ones = {(_Float16)1.0f, (_Float16)1.0f};
+                const h2 pk = {(_Float16)acc[mt][nt][r], (_Float16)acc[mt][nt][r + 1]};
+                s1 = __builtin_amdgcn_fdot2(pk, ones, s1, false);
+                s2 = __builtin_amdgcn_fdot2(pk, pk, s2, false);
+                *reinterpret_cast<h2*>(o0) = pk;
+              } else {
+                typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+                const b2 pk = {(__bf16)acc[mt][nt][r], (__bf16)acc[mt][nt][r + 1]};
+                const float v0 = (float)pk[0], v1 = (float)pk[1];
+                s1 += v0 + v1;
+                s2 = fmaf(v0, v0, fmaf(v1, v1, s2));
+                *reinterpret_cast<b2*>(o0) = pk;
+              }
+            }
+          s1 += __shfl_xor(s1, 32);
+          s2 += __shfl_xor(s2, 32);
+          if (hh == 0) reinterpret_cast<float2*>(smem + R_OFF)[wt * CT + wc * (WN * 32) + nt * 32 + l31 + zl] = float2{s1, s2};
+        }
+        pt_ = ct;
+        pending = true;
+      }
+      WS_TMARK(3)
+      if (++cci == n) {
+        cci = 0;
+        next_tile(ct);
+      }
+      ntaps = nx_ntaps;
+      d = nx_dil;
+      wb = nx_wb;
+      // The previous tile's rows leave at the END of its successor's first step, behind the wait for this step's weight DMA: the
+      // stores then have a whole step to be acknowledged before the next vmcnt(0) (CDNA counts stores in vmcnt too, and a wait
+      // placed right after them exposes the full write latency once per tile).
+      if (pending && cci == (n > 1 ? 1 : 0)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(VQVS_WS_EXP & 4)) store_tile();
+        pending = false;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      } else {
+        sync_all();
+      }
+      WS_TMARK(4)
+    }
+    if (pending) store_tile();
+#ifdef VQVS_TIMING
+    WS_TMARK(0)
+    if (lane == 0 && ((int)blockIdx.x & 15) == 3) {
+      for (int i = 0; i < 5; ++i) atomicAdd(&g_ws_timing[8 + i], tacc[i]);
+      atomicAdd(&g_ws_timing[17], 1ull);
+      atomicAdd(&g_ws_timing[19], (unsigned long long)(te - tb));
+    }
+#endif
+  }
+}
+
+int ws_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("VQVS_WS");  // 0: every convolution on conv_mfma_kernel (A/B measurements)
+    v = e ? atoi(e) : 1;
+  }
+  return v;
+}
+
+int ws_num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 256;
+    n = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+  }
+  return n;
+}
+
+template <int WN>
+constexpr int ws_fixed_lds(bool res) {  // LDS bytes besides resident weights
+  constexpr int CT = 64 * WN;
+  return (res ? 2 * 256 * 64 + 2 * CT * 64 : 2 * (256 * 64 + 3 * CT * 64)) + 128 * (CT * 4 + 16) + 4 * CT * 8;
+}
+constexpr int WS_LDS_MAX = 160 * 1024;
+
+template <typename T, int WN, bool RES>
+int ws_launch(const WsArgs& w, hipStream_t st) {
+  const int lds = ws_fixed_lds<WN>(RES) + (RES ? w.wres_bytes : 0) + w.ss_ring * w.ss_bytes;
+  static bool attr_done = false;
+  if (!attr_done) {
+    VQVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<T, WN, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_MAX));
+    attr_done = true;
+  }
+  const int grid = w.ntiles < ws_num_cus() ? w.ntiles : ws_num_cus();
+  hipLaunchKernelGGL((conv_ws_kernel<T, WN, RES>), dim3(grid), dim3(1024), lds, st, w);
+  VQVS_HIP(hipGetLastError());
+  return 0;
+}
+template <typename T>
+int ws_launch_t(const WsArgs& w, int CT, bool res, hipStream_t st) {
+  if (CT == 128) return res ? ws_launch<T, 2, true>(w, st) : ws_launch<T, 2, false>(w, st);
+  return res ? ws_launch<T, 1, true>(w, st) : ws_launch<T, 1, false>(w, st);
+}
+
+}  // namespace
+
+#ifdef VQVS_TIMING
+int ws_timing_read(unsigned long long* out32, int reset) {
+  VQVS_HIP(hipDeviceSynchronize());
+  VQVS_HIP(hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_ws_timing), 32 * sizeof(unsigned long long)));
+  if (reset) {
+    unsigned long long z[32] = {};
+    VQVS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_ws_timing), z, sizeof(z)));
+  }
+  return 0;
+}
+#endif
+
+// Returns 1 when the launch was taken by the wave-specialised kernel, 0 when the shape is not covered (caller falls back to
+// conv_mfma_kernel), < 0 on error.
+int launch_conv_ws(const ConvArgs& a, int B, int precision, hipStream_t st) {
+  if (!ws_enabled() || precision == 0) return 0;
+  if (a.Cout % 64 != 0 || a.out_f32 || a.epi_gelu || a.nbw || (a.out_rows != 0 && a.out_rows != a.Lout)) return 0;
+  if (a.skip != nullptr && (a.skip_resize != RESIZE_NONE || a.skip_C != a.Cout || a.skip_L != a.Lout)) return 0;
+  const int CT = a.Cout % 128 == 0 ? 128 : 64;
+  WsArgs w{};
+  int dmax = 0, n = 0;
+  for (int s = 0; s < a.nseg; ++s) {
+    const SegDesc& g = a.seg[s];
+    if (g.resize != RESIZE_NONE || g.C % 32 != 0 || (g.ntaps != 1 && g.ntaps != 3) || g.Lsrc != a.Lout) return 0;
+    if ((long long)g.Lsrc * g.Csrc * 2 > 0x7fffffffLL) return 0;
+    WsSeg& q = w.seg[s];
+    q.src = g.src;
+    q.ss = g.ss;
+    q.Csrc = g.Csrc;
+    q.c0 = g.c0;
+    q.nch = g.C / 32;
+    q.ntaps = g.ntaps;
+    q.dil = g.ntaps == 3 ? g.dil : 0;
+    q.ss_stride = g.ss_stride;
+    q.ss_c0 = g.ss_c0;
+    q.ss_lds = w.ss_bytes;
+    if (g.ss != nullptr) w.ss_bytes += g.C * 8;
+    q.wbase = (int)(g.w_off * 2);
+    q.wstep = g.ntaps * a.Cout * 64;
+    q.lds_off = w.wres_bytes;
+    w.wres_bytes += q.nch * q.wstep;
+    if (q.dil > dmax) dmax = q.dil;
+    n += q.nch;
+  }
+  w.nseg = a.nseg;
+  if (a.skip != nullptr) {
+    WsSeg& q = w.seg[w.nseg++];
+    q.src = a.skip;
+    q.ss = nullptr;
+    q.Csrc = a.skip_C;
+    q.c0 = 0;
+    q.nch = CT / 32;
+    q.ntaps = 0;
+    q.dil = 0;
+    n += q.nch;
+  }
+  if (a.tile_rows != 256 - 2 * dmax || a.w_bytes > 0x7fffffffLL || n < 2) return 0;
+  w.nchunks = n;
+  w.w = a.w_hi;
+  w.w_bytes = (int)a.w_bytes;
+  w.bias = a.bias;
+  w.out = a.out;
+  w.stats = a.stats;
+  w.Cout = a.Cout;
+  w.Lout = a.Lout;
+  w.TTO = a.tile_rows;
+  w.ntx = (a.Lout + a.tile_rows - 1) / a.tile_rows;
+  w.nty = a.Cout / CT;
+  w.ntiles = w.ntx * w.nty * B;
+  w.ntiles_stat = a.ntiles;
+  if (w.ntiles <= 0) return 0;
+  // resident weights: one channel tile per launch and everything fits the CU's LDS
+  static const int res_env = getenv("VQVS_WS_RES") ? atoi(getenv("VQVS_WS_RES")) : 1;  // 0: always stream the weights (A/B measurements)
+  if (w.ss_bytes > 8192) return 0;  // (one 16-byte piece per producer thread)
+  w.ss_ring = (long long)w.ntx * w.nty * n >= 4 ? 2 : 4;
+  const int ss_total = w.ss_ring * w.ss_bytes;
+  if ((CT == 128 ? ws_fixed_lds<2>(false) : ws_fixed_lds<1>(false)) + ss_total > WS_LDS_MAX) return 0;
+  const bool res = res_env && w.nty == 1 && (CT == 128 ? ws_fixed_lds<2>(true) : ws_fixed_lds<1>(true)) + w.wres_bytes + ss_total <= WS_LDS_MAX;
+  const int rc = precision == 2 ? ws_launch_t<half_t>(w, CT, res, st) : ws_launch_t<bf16_t>(w, CT, res, st);
+  return rc < 0 ? rc : 1;
+}
+
+}  // namespace vqvs

@@ -79,6 +79,8 @@ struct ConvArgs {
 };
 
 int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st);
+// wave-specialised persistent kernel (conv_ws.hip): 1 = launched, 0 = shape not covered (launch_conv falls back to conv_mfma_kernel), < 0 = error
+int launch_conv_ws(const ConvArgs& a, int B, int precision, hipStream_t st);
 int conv_tile_rows(int dmax, int Cout, int precision);
 
 // ----------------------------------------------------------------------------------
