@@ -115,9 +115,22 @@ int vqvs_encoder_forward(vqvs_model* m, const float* d_x, float* d_z, int B, int
  * torchaudio.functional.amplitude_to_DB does for a 3-D input: its results depend on the batch composition. */
 int vqvs_mfcc_encoder_forward(vqvs_model* m, const float* d_x, float* d_z, int B, int T, void* stream);
 
+/* Testing entry for the same handles: the front end's log-mel rows are INJECTED (d_logmel [B][T/160 + 1][n_mels] f32, version-1
+ * / log_mels front end only) and everything behind them runs as above: DCT to 13 coefficients, `deltas` twice, concatenation
+ * and the convolution stack -- the part of conv_encoder.py:96-110 that is the reference's own code.  With logmel = dct_mat . c the
+ * encoder sees the MFCC tensor c (dct_mat has orthonormal columns), which is how tests/test_conv_mfcc.py holds this path to
+ * fixture F12 (made from the reference with torchaudio.transforms.MFCC stubbed out). */
+int vqvs_mfcc_encoder_forward_logmel(vqvs_model* m, const float* d_logmel, float* d_z, int B, int T, void* stream);
+
 /* y = ResBlock.forward(x, emb)   reference unet.py:307-316 (VQVS_KIND_RESBLOCK handles)
  *   d_x [B,rb_cin,L] f32, d_emb [B,rb_emb_channels] f32 or NULL -> d_y [B,rb_cout,L'] f32 */
 int vqvs_resblock_forward(vqvs_model* m, const float* d_x, const float* d_emb, float* d_y, int B, int L, void* stream);
+
+/* Range guard: the device status word of a handle, read and cleared (synchronises the device).  Bit 0: a GroupNorm partial sum
+ * was not finite -- an activation overflowed the storage type (fp16: 65504) or the input held NaN; bit 1 (VQVS_PREC_F16 only):
+ * a 256-row tile's sum of squares reached 9e8, i.e. an activation may have passed 3e4.  The reference (fp32 throughout,
+ * unet.py:337-349) has no such limit, so a caller that sees a non-zero word must re-run in VQVS_PREC_F32. */
+int vqvs_model_status(vqvs_model* m, unsigned* h_status);
 
 /* ---- classifier guidance (BASELINE config 5) -------------------------------------
  * logits = Classifier.forward(x, ts)   reference models/classifier.py:31-36 (stem :111-121, attention pool

@@ -381,6 +381,103 @@ def gen_uncond_guidance():
          scales=np.array([vq_scale, label_scale]), x0=dec)
 
 
+# ---------------------------------------------------------------- F6b: the headline workload itself
+def gen_sampler_unet64():
+    """BENCH's exact configuration on 2 clips: unet64, 50 steps, t**2 sample-time schedule (README.md:49), constrain=True
+    (diffusion.py:92-133).  ~15 TFLOP of CPU work: minutes, run once."""
+    model = det_model(DiffusionModel("unet", 64))
+    sd = state_of(model)
+    x_T = seeded((2, 1, 64000), 17)
+    tmap = lambda t: t ** 2  # noqa: E731
+    x0, noises = run_ref_sampler(model, x_T, 50, 19, True, tmap)
+    print(f"  unet64 s50_sq_constrain: x0 rms={x0.pow(2).mean().sqrt().item():.4f}")
+    save("f6b_sampler_unet64", x_T_seed=17, noise_seed=19, steps=50, x0=x0.to(torch.float32),
+         noise_checksum=np.array([n.double().sum().item() for n in noises]))
+
+
+# ---------------------------------------------------------------- F11b: decode_uncond_guidance at a real step count
+def gen_uncond_guidance_50():
+    import vq_voice_swap.diffusion.diffusion as dmod
+    import vq_voice_swap.vq_vae as vmod
+
+    model = det_model(VQVAE(base_channels=32, pred_name="unet", num_labels=5))
+    with torch.no_grad():
+        model.vq.dictionary.copy_(seeded(model.vq.dictionary.shape, 77, 0.35))
+    sd = state_of(model)
+    codes = torch.randint(0, 512, (2, 32), generator=torch.Generator().manual_seed(91))
+    labels = torch.tensor([0, 3])
+    steps, vq_scale, label_scale = 50, 1.5, 0.7
+    x_T = seeded((2, 1, 8192), 92)
+    gen = torch.Generator().manual_seed(93)
+    noises = [torch.randn(x_T.shape, generator=gen) for _ in range(steps)]
+    it = iter(noises)
+    orig_rl, orig_r = torch.randn_like, torch.randn
+    dmod.torch.randn_like = lambda t, *a, **k: next(it)
+    vmod.torch.randn = lambda *a, **k: x_T.clone()
+    try:
+        with torch.no_grad():
+            dec = model.decode_uncond_guidance(codes, labels, steps=steps, constrain=True, label_scale=label_scale, vq_scale=vq_scale)
+    finally:
+        dmod.torch.randn_like = orig_rl
+        vmod.torch.randn = orig_r
+    dec2 = ref_cpu.vqvae_decode_uncond_guidance(sd, 32, "exp", codes, labels, steps, x_T, noises, constrain=True,
+                                                label_scale=label_scale, vq_scale=vq_scale)
+    check("decode_uncond_guidance 50 steps", dec, dec2, tol=1e-5)
+    print(f"  x0 rms={dec.pow(2).mean().sqrt().item():.4f}")
+    save("f11b_uncond_guidance_50", x_T_seed=92, noise_seed=93, codes=codes, labels=labels, steps=steps,
+         scales=np.array([vq_scale, label_scale]), x0=dec)
+
+
+# ---------------------------------------------------------------- F12: what IS the reference's own code in ConvMFCCEncoder
+def gen_conv_mfcc_stack():
+    """models/conv_encoder.py:90-133 with torchaudio.transforms.MFCC replaced by a stub that returns an injected [B, 13, frames]
+    tensor (torchaudio is not installed where fixtures are made; the stub exists in this script only): pins invert_ulaw, deltas
+    x 2, the concatenation order, ResConv, the k = 4 / stride-2 convolution and the output convolution.  The MFCC transform itself
+    stays unpinned."""
+    import types
+
+    captured = {}
+
+    class StubMFCC(torch.nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+            self.kwargs = k
+
+        def forward(self, wave):
+            captured["wave"] = wave.detach().clone()
+            return captured["inject"]
+
+    ta = types.ModuleType("torchaudio")
+    tt = types.ModuleType("torchaudio.transforms")
+    tt.MFCC = StubMFCC
+    ta.transforms = tt
+    sys.modules["torchaudio"] = ta
+    sys.modules["torchaudio.transforms"] = tt
+    from vq_voice_swap.models.conv_encoder import ConvMFCCEncoder  # reference
+
+    out = {}
+    for tag, ulaw, T in (("ulaw_even", True, 4000), ("ulaw_odd", True, 4160), ("linear_even", False, 64000)):
+        frames = T // 160 + 1
+        enc = ConvMFCCEncoder(32, out_channels=512, input_ulaw=ulaw)
+        det_init_((("encoder." + k, v) for k, v in enc.state_dict().items()))
+        sd = {"encoder." + k: v.detach().clone() for k, v in enc.state_dict().items()}
+        x = (0.4 * seeded((2, 1, T), 300 + len(out))).clamp(-1, 1)
+        mf = seeded((2, 13, frames), 400 + len(out), 3.0)
+        captured["inject"] = mf
+        with torch.no_grad():
+            z = enc(x)
+        z2 = ref_cpu.conv_mfcc_encoder(sd, x, version=1, input_ulaw=ulaw, mfcc_override=mf)
+        check("conv-mfcc stack " + tag, z, z2, tol=1e-5)
+        want_wave = ref_cpu.invert_ulaw(x)[:, 0] if ulaw else x[:, 0]
+        check("conv-mfcc invert_ulaw " + tag, captured["wave"], want_wave, tol=1e-7)
+        out[tag + ".x"] = x
+        out[tag + ".mfcc"] = mf
+        out[tag + ".wave_seen_by_mfcc"] = captured["wave"]
+        out[tag + ".z"] = z
+        print(f"  {tag}: frames={frames} z {tuple(z.shape)} rms={z.pow(2).mean().sqrt().item():.4f}")
+    save("f12_conv_mfcc_stack", **out)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     if not only or "resblocks" in only:
@@ -403,4 +500,10 @@ if __name__ == "__main__":
         gen_ddpm_previous_cos()
     if not only or "uncond" in only:
         gen_uncond_guidance()
+    if not only or "uncond50" in only:
+        gen_uncond_guidance_50()
+    if not only or "mfccstack" in only:
+        gen_conv_mfcc_stack()
+    if "unet64" in only:  # (minutes of CPU time: only on request; the committed fixture is re-verifiable with this argument)
+        gen_sampler_unet64()
     print("ok")

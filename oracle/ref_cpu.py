@@ -527,14 +527,15 @@ def mfcc_transform(wave: Tensor, sd: State, cfg: dict, prefix: str = "") -> Tens
 
 
 def conv_mfcc_encoder(sd: State, x: Tensor, version: int = 1, input_ulaw: bool = True, prefix: str = "encoder.",
-                      probe: Optional[Callable[[str, Tensor], None]] = None) -> Tensor:
+                      probe: Optional[Callable[[str, Tensor], None]] = None, mfcc_override: Optional[Tensor] = None) -> Tensor:
     """ConvMFCCEncoder.forward (conv_encoder.py:90-110): [N,1,T] -> [N, out_channels, (T // hop + 1 - 2) // 2 + 1]."""
     p = prefix
     cfg = mfcc_config(version)
     assert x.shape[1] == 1, "input must only have one channel"
     if input_ulaw:
         x = invert_ulaw(x)
-    h = mfcc_transform(x[:, 0, :], sd, cfg, p)
+    # (mfcc_override: the [N, 13, frames] tensor the transform would return -- fixture F12 pins everything AROUND the transform)
+    h = mfcc_transform(x[:, 0, :], sd, cfg, p) if mfcc_override is None else mfcc_override
     deriv = deltas(h)
     accel = deltas(deriv)
     h = torch.cat([h, deriv, accel], dim=1)

@@ -166,3 +166,23 @@ def test_guided_sampling_ten_steps_in_both_gate_modes():
         errs[prec] = rms(got - want)
         assert errs[prec] < 1e-3, errs
     assert rms(want - plain) > 5 * max(errs.values()), ("guidance term too small for the comparison to mean anything", errs, rms(want - plain))
+
+
+@pytest.mark.gpu
+def test_guidance_gradient_is_batch_independent_at_full_size():
+    """BASELINE config 5's classifier at its full size (classifier32, B = 32 clips of T = 64000, fp16 mode): the resident backward
+    arena of a 32-clip call must give clips 0 / 17 / 31 BITWISE the gradient of a 1-clip call (sample_diffusion.py:34-42,
+    models/classifier.py:111-121 are per clip: nothing mixes clips)."""
+    dev = torch.device("cuda:0")
+    clf = Classifier(num_labels=251, base_channels=32)
+    det_init_(clf.state_dict().items())
+    clf.eval()
+    clf.set_precision("fp16")
+    x = seeded((32, 1, 64000), 41).to(dev)
+    ts = torch.linspace(0.05, 0.95, 32).to(dev)
+    labels = (torch.arange(32) * 7 % 251).to(dev)
+    g_all, logits_all = clf.log_prob_grad(x, ts, labels, scale=1.0, return_logits=True)
+    assert g_all.shape == x.shape and bool(torch.isfinite(g_all).all())
+    for i in (0, 17, 31):
+        g1, l1 = clf.log_prob_grad(x[i:i + 1], ts[i:i + 1], labels[i:i + 1], scale=1.0, return_logits=True)
+        assert torch.equal(g1[0], g_all[i]) and torch.equal(l1[0], logits_all[i]), i

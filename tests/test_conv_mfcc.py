@@ -150,3 +150,31 @@ def test_predictor_with_mfcc_rate_conditioning_vs_oracle():
     wav = (0.3 * seeded((1, 1, T), 14)).clamp(-1, 1)
     out = model.decode(model.encode(wav.to(dev)), torch.tensor([1], device=dev), steps=2, constrain=True, seed=5)
     assert out.shape == (1, 1, T) and bool(torch.isfinite(out).all())
+
+
+@pytest.mark.gpu
+def test_hip_conv_stack_vs_reference_fixture(golden):
+    """F12 through the C ABI (vqvs_mfcc_encoder_forward_logmel): deltas x 2, concatenation and the convolution stack of the HIP
+    encoder against the REFERENCE's own output on an injected MFCC tensor (conv_encoder.py:97-110), and -- with a dictionary made of
+    the reference's z vectors, so that every position has a guaranteed margin -- VQ codes with ZERO mismatches."""
+    dev = torch.device("cuda:0")
+    z = golden("f12_conv_mfcc_stack")
+    for tag, enc_name, T in (("ulaw_even", "conv-mfcc-ulaw", 4000), ("ulaw_odd", "conv-mfcc-ulaw", 4160), ("linear_even", "conv-mfcc-linear", 64000)):
+        model = det_encoder(enc_name)
+        want = torch.from_numpy(z[tag + ".z"])
+        got = model.encoder.forward_from_mfcc(torch.from_numpy(z[tag + ".mfcc"]).to(dev), T).cpu()
+        assert got.shape == want.shape
+        assert rel_rms(got, want) < 1e-4, (tag, rel_rms(got, want))
+        # VQ on margin-guaranteed inputs: the dictionary holds the reference's own z vectors (+ far-away fillers)
+        vecs = want.permute(0, 2, 1).reshape(-1, want.shape[1])
+        dic = 10.0 * seeded((512, want.shape[1]), 555)
+        n = min(len(vecs), 512)
+        dic[:n] = vecs[:n]
+        codes_want = ref_cpu.vq_encode(dic, want)
+        d = ref_cpu.vq_distances(dic, vecs)
+        top2 = torch.topk(d, 2, dim=-1, largest=False).values
+        assert ((top2[:, 1] - top2[:, 0]) > 1e-3 * top2[:, 1].abs().clamp_min(1e-6))[:n].all(), "fixture margins"
+        with torch.no_grad():
+            model.vq.dictionary.copy_(dic)
+        codes = model.vq.encode(got.to(dev)).cpu()
+        assert torch.equal(codes.reshape(-1)[:n], codes_want.reshape(-1)[:n]), tag

@@ -140,3 +140,38 @@ def test_decode_uncond_guidance_matches_reference(golden, lib_built):
     dec = ref_cpu.vqvae_decode_uncond_guidance(sd, 32, "exp", torch.from_numpy(z["codes"]), torch.from_numpy(z["labels"]), steps, x_T, noises,
                                                constrain=True, label_scale=label_scale, vq_scale=vq_scale)
     assert (dec - torch.from_numpy(z["x0"])).abs().max().item() <= 1e-5
+
+
+def test_decode_uncond_guidance_50_steps_matches_reference(golden, lib_built):
+    """F11b: the same path at a real step count (50), from the reference's own decode_uncond_guidance (vq_vae.py:147-220)."""
+    z = golden("f11b_uncond_guidance_50")
+    sd = det_sd(predictor_cfg(32, cond=512, labels=5), "predictor.")
+    sd["vq.dictionary"] = seeded((512, 512), 77, 0.35)
+    steps = int(z["steps"])
+    x_T = seeded((2, 1, 8192), int(z["x_T_seed"]))
+    gen = torch.Generator().manual_seed(int(z["noise_seed"]))
+    noises = [torch.randn(x_T.shape, generator=gen) for _ in range(steps)]
+    vq_scale, label_scale = (float(v) for v in z["scales"])
+    dec = ref_cpu.vqvae_decode_uncond_guidance(sd, 32, "exp", torch.from_numpy(z["codes"]), torch.from_numpy(z["labels"]), steps, x_T, noises,
+                                               constrain=True, label_scale=label_scale, vq_scale=vq_scale)
+    assert (dec - torch.from_numpy(z["x0"])).abs().max().item() <= 1e-5
+
+
+def test_conv_mfcc_stack_matches_reference(golden, lib_built):
+    """F12: everything of ConvMFCCEncoder.forward that is the reference's own code (conv_encoder.py:90-133: invert_ulaw, deltas x 2,
+    concatenation order, ResConv, the k = 4 / stride-2 convolution, the output convolution) on an injected MFCC tensor.  The fixture
+    was made from the reference with torchaudio.transforms.MFCC stubbed out; the transform itself stays unpinned."""
+    from vq_voice_swap_amd.det_init import det_tensor
+
+    z = golden("f12_conv_mfcc_stack")
+    cfg = _native.Cfg()
+    cfg.kind, cfg.base_channels, cfg.in_channels, cfg.out_channels = _native.KIND_MFCC_ENCODER, 32, 1, 512
+    cfg.reserved[1], cfg.reserved[2] = 1, 1
+    sd = {"encoder." + n: det_tensor("encoder." + n, s) for n, s in _native.param_table(cfg) if ".mfcc." not in n and not n.startswith("mfcc.")}
+    for tag, ulaw in (("ulaw_even", True), ("ulaw_odd", True), ("linear_even", False)):
+        x = torch.from_numpy(z[tag + ".x"])
+        mf = torch.from_numpy(z[tag + ".mfcc"])
+        got = ref_cpu.conv_mfcc_encoder(sd, x, version=1, input_ulaw=ulaw, mfcc_override=mf)
+        assert (got - torch.from_numpy(z[tag + ".z"])).abs().max().item() <= 1e-5, tag
+        seen = ref_cpu.invert_ulaw(x)[:, 0] if ulaw else x[:, 0]
+        assert (seen - torch.from_numpy(z[tag + ".wave_seen_by_mfcc"])).abs().max().item() <= 1e-7, tag

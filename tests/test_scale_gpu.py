@@ -115,3 +115,45 @@ def test_config4_base64_encoder_vq_and_cond_forward(dev):
         model.set_precision(prec)
         got = model.predictor(x.to(dev), ts.to(dev), cond=cond.to(dev), labels=labels.to(dev)).cpu()
         assert rel_rms(got, want) < GATE[prec], (prec, rel_rms(got, want))
+
+
+def test_headline_workload_vs_reference_fixture(golden):
+    """F6b: BENCH's exact configuration (unet64, 50 steps, t**2 sample-time schedule, constrain) on two clips, against the
+    REFERENCE's own ddpm_sample output (diffusion.py:92-133 with README.md:49's schedule), in the parity mode and in the benchmarked
+    fp16 mode: <= 1e-3 waveform RMS each."""
+    import numpy as np
+
+    dev = torch.device("cuda:0")
+    z = golden("f6b_sampler_unet64")
+    model = det_model(DiffusionModel("unet", 64))
+    steps = int(z["steps"])
+    x_T = seeded((2, 1, 64000), int(z["x_T_seed"]))
+    gen = torch.Generator().manual_seed(int(z["noise_seed"]))
+    noises = [torch.randn(x_T.shape, generator=gen) for _ in range(steps)]
+    assert np.allclose([n.double().sum().item() for n in noises], z["noise_checksum"], atol=1e-6), "noise stream differs"
+    want = torch.from_numpy(z["x0"])
+    for prec in ("fp32", "fp16"):
+        model.set_precision(prec)
+        got = model.diffusion.ddpm_sample(x_T.to(dev), model.predictor, steps, constrain=True, schedule=lambda t: t ** 2,
+                                          noise=[n.to(dev) for n in noises]).cpu()
+        assert rms(got - want) < WAVE_RMS, (prec, rms(got - want))
+
+
+def test_fp16_range_guard_trips():
+    """An fp16-mode model whose activations leave fp16's range must raise instead of returning garbage (the statistics pass of
+    every GroupNorm flags non-finite or >= 3e4-class partial sums; vqvs_model_status); the same weights run clean in fp32."""
+    from vq_voice_swap_amd import _native
+
+    dev = torch.device("cuda:0")
+    model = det_model(DiffusionModel("unet", 32))
+    x_T = seeded((2, 1, 4096), 5)
+    noises = [seeded((2, 1, 4096), 100 + i).to(dev) for i in range(3)]
+    model.set_precision("fp16")
+    model.diffusion.ddpm_sample(x_T.to(dev), model.predictor, 3, constrain=True, noise=noises)  # sane weights: no trip
+    with torch.no_grad():
+        model.predictor.in_conv.weight.mul_(3.0e5)  # pushes the first tensor far beyond 65504
+    with pytest.raises(_native.NativeError, match="range guard"):
+        model.diffusion.ddpm_sample(x_T.to(dev), model.predictor, 3, constrain=True, noise=noises)
+    model.set_precision("fp32")
+    out = model.diffusion.ddpm_sample(x_T.to(dev), model.predictor, 3, constrain=True, noise=noises)
+    assert bool(torch.isfinite(out).all())

@@ -47,7 +47,7 @@ class Cfg(C.Structure):
 
 EXPORTS = [
     "vqvs_param_count", "vqvs_param_info", "vqvs_model_create", "vqvs_model_destroy", "vqvs_model_device_bytes",
-    "vqvs_unet_forward", "vqvs_encoder_forward", "vqvs_mfcc_encoder_forward", "vqvs_resblock_forward", "vqvs_classifier_forward",
+    "vqvs_unet_forward", "vqvs_encoder_forward", "vqvs_mfcc_encoder_forward", "vqvs_mfcc_encoder_forward_logmel", "vqvs_model_status", "vqvs_resblock_forward", "vqvs_classifier_forward",
     "vqvs_classifier_guidance", "vqvs_encpred_forward", "vqvs_encpred_guidance", "vqvs_ddpm_step", "vqvs_ddpm_mean",
     "vqvs_ddpm_guided_eps", "vqvs_randn", "vqvs_vq_argmin", "vqvs_vq_embed", "vqvs_debug_tap_count",
     "vqvs_debug_tap_info", "vqvs_debug_tap_rows", "vqvs_debug_read_tap", "vqvs_debug_read_embedding", "vqvs_forward_kernel_count", "vqvs_forward_model_bytes",
@@ -97,6 +97,8 @@ def lib():
     L.vqvs_unet_forward.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp]
     L.vqvs_encoder_forward.argtypes = [vp, vp, vp, i32, i32, vp]
     L.vqvs_mfcc_encoder_forward.argtypes = [vp, vp, vp, i32, i32, vp]
+    L.vqvs_mfcc_encoder_forward_logmel.argtypes = [vp, vp, vp, i32, i32, vp]
+    L.vqvs_model_status.argtypes = [vp, vp]
     L.vqvs_resblock_forward.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     L.vqvs_classifier_forward.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     L.vqvs_classifier_guidance.argtypes = [vp, vp, vp, vp, f32, vp, vp, i32, i32, vp]
@@ -198,6 +200,12 @@ class Handle:
     def ptr(self):
         return self._h
 
+    def status(self) -> int:
+        """Device status word (vqvs_model_status): read and cleared; synchronises the device."""
+        w = C.c_uint(0)
+        check(lib().vqvs_model_status(self.ptr, C.byref(w)))
+        return int(w.value)
+
     def close(self):
         if getattr(self, "_h", None):
             lib().vqvs_model_destroy(self._h)
@@ -291,16 +299,18 @@ _range_checked = {}
 def check_index_range(t, n: int, what: str) -> None:
     """Raise IndexError, as nn.Embedding / F.embedding do (reference unet.py:45, vq.py:108), when an index tensor holds
     values outside [0, n).  The kernels clamp instead of faulting, which would turn a caller bug into plausible audio.
-    The check costs one device->host sync, so a tensor that was already checked (same storage, same version -- the
-    labels of a sampling loop) is not checked again."""
-    key = (what, t.data_ptr(), t._version, t.numel(), n)
-    if _range_checked.get(what) == key:
+    The check costs one device->host sync, so the SAME tensor object at the same version (the labels of a sampling loop, passed
+    again every step) is not checked twice; a new tensor -- even one the allocator places at the old address -- always is."""
+    import weakref
+
+    prev = _range_checked.get(what)
+    if prev is not None and prev[0]() is t and prev[1:] == (t._version, t.numel(), n):
         return
     if t.numel():
         lo, hi = int(t.min().item()), int(t.max().item())
         if lo < 0 or hi >= n:
             raise IndexError(f"{what}: index out of range (values span [{lo}, {hi}], valid range is [0, {n - 1}])")
-    _range_checked[what] = key
+    _range_checked[what] = (weakref.ref(t), t._version, t.numel(), n)
 
 
 def require_cuda(*tensors) -> None:

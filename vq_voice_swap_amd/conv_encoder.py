@@ -115,6 +115,22 @@ class ConvMFCCEncoder(_NativeModule):
             _native.check(_native.lib().vqvs_mfcc_encoder_forward(h.ptr, x.data_ptr(), z.data_ptr(), B, T, _native._stream_ptr()))
         return z
 
+    def forward_from_mfcc(self, mfcc: torch.Tensor, T: int) -> torch.Tensor:
+        """Testing entry (`vqvs_mfcc_encoder_forward_logmel`): run everything BEHIND the MFCC transform -- `deltas` twice, the
+        concatenation, the convolution stack (reference conv_encoder.py:97-109) -- on an injected [B, 13, T // 160 + 1] coefficient
+        tensor.  The kernels start from log-mel rows, so the injection is logmel = dct_mat . mfcc (orthonormal columns: the
+        DCT gives the coefficients back).  Version-1 front end only."""
+        _native.require_cuda(mfcc)
+        B, n, frames = mfcc.shape
+        assert n == 13 and frames == T // (self.input_rate // self.mfcc_rate) + 1 and self.version == 1
+        dct = self.mfcc.dct_mat.to(mfcc.device, torch.float64)  # [n_mels, 13]
+        logmel = torch.einsum("mk,bkf->bfm", dct, mfcc.to(torch.float64)).to(torch.float32).contiguous()  # [B, frames, n_mels]
+        h = self.handle(mfcc.device, B, T)
+        z = torch.empty(B, self.out_channels, self.out_length(T), device=mfcc.device, dtype=torch.float32)
+        with torch.cuda.device(mfcc.device):
+            _native.check(_native.lib().vqvs_mfcc_encoder_forward_logmel(h.ptr, logmel.data_ptr(), z.data_ptr(), B, T, _native._stream_ptr()))
+        return z
+
     @property
     def downsample_rate(self) -> int:
         return self.input_rate // (self.mfcc_rate // 2)

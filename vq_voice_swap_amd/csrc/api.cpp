@@ -158,6 +158,19 @@ int vqvs_mfcc_encoder_forward(vqvs_model* m, const float* d_x, float* d_z, int B
   return run_model(m, c);
 }
 
+int vqvs_mfcc_encoder_forward_logmel(vqvs_model* m, const float* d_logmel, float* d_z, int B, int T, void* stream) {
+  if (int e = check_run(m, VQVS_KIND_MFCC_ENCODER, B, T)) return e;
+  if (!d_logmel || !d_z) VQVS_FAIL(VQVS_ERR_ARG, "logmel and z must be non-NULL");
+  if (T < 800) VQVS_FAIL(VQVS_ERR_ARG, "T=%d is too short for the MFCC front end (needs at least 800 samples)", T);
+  RunCtx c;
+  c.B = B;
+  c.Lbase = T;
+  c.logmel = d_logmel;
+  c.out = d_z;
+  c.st = reinterpret_cast<hipStream_t>(stream);
+  return run_model(m, c);
+}
+
 int vqvs_resblock_forward(vqvs_model* m, const float* d_x, const float* d_emb, float* d_y, int B, int L, void* stream) {
   if (int e = check_run(m, VQVS_KIND_RESBLOCK, B, L)) return e;
   if (!d_x || !d_y) VQVS_FAIL(VQVS_ERR_ARG, "x and y must be non-NULL");
@@ -376,6 +389,19 @@ int vqvs_op_desc(const vqvs_model* m, int i, char* out, int cap) {
   if (!m || i < 0 || i >= (int)m->meta.size() || !out || cap < 1) VQVS_FAIL(VQVS_ERR_ARG, "bad argument");
   strncpy(out, m->meta[i].desc.c_str(), cap - 1);
   out[cap - 1] = 0;
+  return 0;
+}
+
+// Device status word of the handle (synchronises the device; the word is cleared): bit 0 = a GroupNorm partial was not finite
+// (an activation overflowed the storage type, or NaN input), bit 1 = fp16 mode, a tile's sum of squares reached 9e8 (an
+// activation may be beyond 3e4 of fp16's 65504).  Callers check it once per sample, not per step.
+int vqvs_model_status(vqvs_model* m, unsigned* h_status) {
+  if (!m || !h_status) VQVS_FAIL(VQVS_ERR_ARG, "NULL argument");
+  *h_status = 0;
+  if (m->status_misc_off == (size_t)-1) return 0;
+  unsigned* d = reinterpret_cast<unsigned*>(reinterpret_cast<float*>(m->d_arena + m->misc_off) + m->status_misc_off);
+  VQVS_HIP(hipMemcpy(h_status, d, sizeof(unsigned), hipMemcpyDeviceToHost));
+  if (*h_status) VQVS_HIP(hipMemset(d, 0, sizeof(unsigned)));
   return 0;
 }
 

@@ -75,6 +75,7 @@ struct WsSeg {
   const void* src;   // [B][Lout][Csrc] of T
   const float2* ss;  // (scale, shift) rows [B][ss_stride], or nullptr = raw (no prologue)
   int Csrc;
+  int clip_bytes;    // Lout * Csrc * sizeof(T): bytes of one clip's rows
   int c0;            // first source channel (identity segment: relative to the output channel tile)
   int nch;           // chunks of 32 channels
   int ntaps;         // 3, 1, or 0 = identity segment (weights = the identity block, written by the producers)
@@ -215,45 +216,44 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
     struct SegF {
       const void* src;
       const float2* ss;
-      int Csrc, c0, nch, ntaps, dil, ss_stride, ss_c0, ss_lds;
+      int Csrc, clip_bytes, c0, nch, ntaps, dil, ss_lds;
     };
-    auto fetch = [&](int sg) -> SegF {
-      return SegF{WS_SEGF(sg, src), WS_SEGF(sg, ss), WS_SEGF(sg, Csrc), WS_SEGF(sg, c0), WS_SEGF(sg, nch),
-                  WS_SEGF(sg, ntaps), WS_SEGF(sg, dil), WS_SEGF(sg, ss_stride), WS_SEGF(sg, ss_c0), WS_SEGF(sg, ss_lds)};
+    auto fetch = [&](int sg) -> SegF {  // (one batch of scalar loads from the argument block, issued a segment ahead of its use)
+      const WsSeg& g = a.seg[sg];
+      return SegF{g.src, g.ss, g.Csrc, g.clip_bytes, g.c0, g.nch, g.ntaps, g.dil, g.ss_lds};
     };
     SegF nx = fetch(0);
     Prep cur;
     int cur_xf = 0, cur_id = 0, cur_idch = 0;  // (wave-uniform parts of meta, kept scalar)
     int ss_clip = -1;  // clip whose (scale, shift) table was written last
     unsigned cur_valid = 0;
+    auto refresh_ss = [&]() {
+      // first chunk of a new clip: its (scale, shift) rows (every prologue segment's) go to LDS once -- the producers then read
+      // them with ds_read instead of four more global loads per chunk and thread.  Slot b % ring: chunks of at most `ring`
+      // clips are in flight (host: ring = 4 when a clip can take fewer than four steps).
+      char* const tab = smem + SS_OFF + (lt.b & (a.ss_ring - 1)) * a.ss_bytes;
+      for (int sg = 0; sg < a.nseg; ++sg) {
+        const WsSeg& g = a.seg[sg];
+        if (g.ss == nullptr) continue;
+        const char* const row = reinterpret_cast<const char*>(g.ss + (size_t)((unsigned)lt.b * (unsigned)g.ss_stride + (unsigned)g.ss_c0));
+        if (pt * 16 < g.nch * 256) *reinterpret_cast<f32x4*>(tab + g.ss_lds + pt * 16) = *reinterpret_cast<const f32x4*>(row + pt * 16);
+      }
+    };
     auto enter = [&]() {  // the cursor has just moved to (lt, lseg, chunk 0)
       const SegF f = nx;
       const int L = a.Lout;
-      const unsigned long long clip = reinterpret_cast<unsigned long long>(f.src) + (unsigned long long)((unsigned)lt.b * (unsigned)L) * (unsigned)(f.Csrc * 2);
+      const unsigned long long clip = reinterpret_cast<unsigned long long>(f.src) + (unsigned long long)(unsigned)lt.b * (unsigned)f.clip_bytes;
       // raw buffer descriptor of this clip's rows: out-of-range rows (before / after the clip) read as zero
       cur.rs[0] = (int)(unsigned)clip;
       cur.rs[1] = (int)((unsigned)(clip >> 32) & 0xffffu);
-      cur.rs[2] = L * f.Csrc * 2;
+      cur.rs[2] = f.clip_bytes;
       cur.rs[3] = 0x00020000;
       const int tm0 = lt.tx * a.TTO - f.dil + r0, tm1 = tm0 + 128;  // time of this thread's two rows
       cur.off0 = (tm0 * f.Csrc + f.c0 + (f.ntaps == 0 ? lt.ty * CT : 0) + oct * 8) * 2;
       cur.off1 = cur.off0 + 256 * f.Csrc;
-      if (lseg == 0 && lt.b != ss_clip) {
-        // first chunk of a new clip: its (scale, shift) rows (every prologue segment's) go to LDS once -- the producers then read
-        // them with ds_read instead of four more global loads per chunk and thread.  Slot b % ring: chunks of at most `ring`
-        // clips are in flight (host: ring = 4 when a clip can take fewer than four steps).
+      if (__builtin_expect(lseg == 0 && lt.b != ss_clip, 0)) {
         ss_clip = lt.b;
-        const int nb = a.ss_bytes;
-        if (pt * 16 < nb) {
-          // which segment does byte pt * 16 of the table belong to?
-          int sg = 0;
-#pragma unroll
-          for (int k = 1; k < 4; ++k)
-            if (k < a.nseg && WS_SEGF(k, ss) != nullptr && pt * 16 >= WS_SEGF(k, ss_lds)) sg = k;
-          const float2* const row = WS_SEGF(sg, ss) + (size_t)((unsigned)lt.b * (unsigned)WS_SEGF(sg, ss_stride) + (unsigned)WS_SEGF(sg, ss_c0));
-          const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(row) + (pt * 16 - WS_SEGF(sg, ss_lds)));
-          *reinterpret_cast<f32x4*>(smem + SS_OFF + (lt.b & (a.ss_ring - 1)) * nb + pt * 16) = v;
-        }
+        refresh_ss();
       }
       cur.ssaddr = SS_OFF + (lt.b & (a.ss_ring - 1)) * a.ss_bytes + f.ss_lds + oct * 64;
       cur_xf = f.ss != nullptr ? 1 : 0;
@@ -362,6 +362,7 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
       issue(R1, p1);
       const Prep p2 = prepare();
       issue(R2, p2);
+
     }
     int q = 0;
     WS_TMARK(2)
@@ -422,8 +423,11 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(smem + WS_OFF + slot * WS_STRIDE + p * 1024), 16, voff, 0, 0, 0);
       }
     };
-    auto sync_all = [&]() {  // + this wave's weight DMA has landed
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    auto sync_all = [&]() {  // + this wave's weight DMA has landed (streaming form; with resident weights nothing waits for VMEM:
+      if constexpr (RES)     //   the tile stores drain on their own, overlapping the producers' loads)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     };
@@ -487,7 +491,8 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
       int nch, ntaps, dil, wbase, wstep, lds_off;
     };
     auto fetchw = [&](int sg) -> SegW {
-      return SegW{WS_SEGF(sg, nch), WS_SEGF(sg, ntaps), WS_SEGF(sg, dil), WS_SEGF(sg, wbase), WS_SEGF(sg, wstep), WS_SEGF(sg, lds_off)};
+      const WsSeg& g = a.seg[sg];
+      return SegW{g.nch, g.ntaps, g.dil, g.wbase, g.wstep, g.lds_off};
     };
     int dseg = 0, dch = 0;
     SegW dw = fetchw(0), dnx = fetchw(a.nseg > 1 ? 1 : 0);
@@ -524,6 +529,7 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
     dma_advance();
     float bj[WN];
     int bias_ty = -1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // first chunk's (or all resident) weights have landed
     sync_all();
     WS_TMARK(4)
     for (int g = 0; g < Q; ++g) {
@@ -643,7 +649,7 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
       // stores then have a whole step to be acknowledged before the next vmcnt(0) (CDNA counts stores in vmcnt too, and a wait
       // placed right after them exposes the full write latency once per tile).
       if (pending && cci == (n > 1 ? 1 : 0)) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (!RES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!(VQVS_WS_EXP & 4)) store_tile();
         pending = false;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -743,6 +749,7 @@ int launch_conv_ws(const ConvArgs& a, int B, int precision, hipStream_t st) {
     q.src = g.src;
     q.ss = g.ss;
     q.Csrc = g.Csrc;
+    q.clip_bytes = g.Lsrc * g.Csrc * 2;
     q.c0 = g.c0;
     q.nch = g.C / 32;
     q.ntaps = g.ntaps;
@@ -764,6 +771,7 @@ int launch_conv_ws(const ConvArgs& a, int B, int precision, hipStream_t st) {
     q.src = a.skip;
     q.ss = nullptr;
     q.Csrc = a.skip_C;
+    q.clip_bytes = a.skip_L * a.skip_C * 2;
     q.c0 = 0;
     q.nch = CT / 32;
     q.ntaps = 0;

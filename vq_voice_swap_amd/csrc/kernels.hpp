@@ -122,6 +122,8 @@ struct GnArgs {  // per-(clip,channel) scale/shift of GroupNorm [+FiLM]; nn.Grou
   int film_stride, film_off;
   float2* ss;          // out [B][Ctot]
   float2* mr;          // optional out [B][Ctot]: (mean, rstd) of the channel's group (kept for the backward pass)
+  unsigned* status;    // device status word of the handle: bit 0 is set when a partial is not finite, bit 1 (fp16 mode, `guard`)
+  int guard;           // when a 256-row tile's sum of squares reaches 9e8, i.e. an activation may have passed 3e4 of fp16's 65504
 };
 int launch_gn_prepare(const GnArgs& a, int B, hipStream_t st);
 

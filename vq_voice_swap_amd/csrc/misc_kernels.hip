@@ -160,6 +160,7 @@ __global__ __launch_bounds__(256) void gn_prepare_kernel(const GnArgs a) {
     const int nsl = 256 / cw;  // tile slices per channel
     const int c = c_lo + c0 + tid % cw, sl = tid / cw;
     double s1 = 0.0, s2 = 0.0;
+    unsigned bad = 0;
     if (sl < nsl) {
       const bool second = c >= C0;
       const GnSrc g = second ? a.src[1] : a.src[0];
@@ -169,10 +170,15 @@ __global__ __launch_bounds__(256) void gn_prepare_kernel(const GnArgs a) {
         const float2 q = *reinterpret_cast<const float2*>(p + ((size_t)t * g.C + cl) * 2);
         s1 += (double)q.x;
         s2 += (double)q.y;
+        // range guard (the statistics are fp32 sums of the stored values): a non-finite partial means an activation overflowed the
+        // storage type; in the fp16 mode a tile whose sum of squares reaches 9e8 may hold an element beyond 3e4 (of 65504)
+        if (!(fabsf(q.x) <= 3.0e38f) || !(q.y <= 3.0e38f)) bad |= 1u;
+        if (a.guard && q.y >= 9.0e8f) bad |= 2u;
       }
       part[tid * 2] = s1;
       part[tid * 2 + 1] = s2;
     }
+    if (bad && a.status) atomicOr(a.status, bad);
     __syncthreads();
     if (tid < cw) {
       double t1 = 0.0, t2 = 0.0;

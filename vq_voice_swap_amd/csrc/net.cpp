@@ -278,6 +278,15 @@ class Builder {
     misc_floats += (floats + 63) & ~(size_t)63;
     return off;
   }
+  // the handle's device status word (range guard of gn_prepare; read and cleared by vqvs_model_status)
+  size_t status_off() {
+    if (status_off_ == (size_t)-1) {
+      status_off_ = alloc_misc(64);
+      m_->status_misc_off = status_off_;
+    }
+    return status_off_;
+  }
+  size_t status_off_ = (size_t)-1;
 
   // ---- pointer resolution at run time ------------------------------------------------
   // (regions are laid out after planning: [activations | stats | ss | misc])
@@ -300,6 +309,8 @@ class Builder {
     std::vector<TensorH> S = srcs;
     std::vector<int> SR;
     for (auto& t : srcs) SR.push_back(stat_rows(t));
+    const size_t st_off = status_off();
+    const int guard = m_->cfg.precision == VQVS_PREC_F16 ? 1 : 0;
     m_->meta.push_back({"gn_prepare", gn_name + " C=" + std::to_string(Ctot) + " L>>" + std::to_string(lshift), 0, 0, 0});
     m_->add_op([=](const RunCtx& c) -> int {
       GnArgs a{};
@@ -316,6 +327,8 @@ class Builder {
       a.film_off = film_off;
       a.ss = reinterpret_cast<float2*>(self->ssp(ss_off));
       a.mr = want_mr ? reinterpret_cast<float2*>(self->ssp(mr_off)) : nullptr;
+      a.status = reinterpret_cast<unsigned*>(self->miscp(st_off));
+      a.guard = guard;
       return launch_gn_prepare(a, c.B, c.st);
     });
   }
@@ -1383,6 +1396,12 @@ int build_model(vqvs_model* m, const float* const* hp) {
     TensorH feat = b.new_tensor(64, LEN_FRAMES, false, false);  // fp32 handle: the activation type is float
     m->meta.push_back({"mfcc_logmel", "n_fft=" + std::to_string(n_fft) + " mels=" + std::to_string(n_mels), 0, 4.0, 0});
     m->add_op([=](const RunCtx& r) -> int {
+      if (r.logmel != nullptr) {  // testing entry (vqvs_mfcc_encoder_forward_logmel): injected log-mel rows, the transform is skipped
+        if (db) VQVS_FAIL(-1, "the injected log-mel entry exists for the log_mels (version 1) front end only");
+        VQVS_HIP(hipMemcpyAsync(bp->miscp(logmel_off), r.logmel, (size_t)r.B * shiftL(r.Lbase, LEN_FRAMES) * n_mels * sizeof(float),
+                                hipMemcpyDeviceToDevice, r.st));
+        return 0;
+      }
       MfccArgs a{};
       a.x = r.x;
       a.twiddle = reinterpret_cast<const double*>(bp->wp(tw_off));

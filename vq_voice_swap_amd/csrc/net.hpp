@@ -43,6 +43,7 @@ struct RunCtx {
   const float* cond = nullptr;
   const int64_t* labels = nullptr;
   const float* emb = nullptr;  // resblock handle: external embedding
+  const float* logmel = nullptr;  // MFCC encoder handle, testing entry: [B][frames][n_mels] log-mel rows replacing the front end's
   float* out = nullptr;
   // classifier handles: logits [B][num_labels]; with backward, grad_out [B][T] = gscale * d log p(labels) / dx
   bool backward = false;
@@ -95,6 +96,7 @@ struct vqvs_model {
     double flops = 0;      // per clip per unit length
   } cost;
   int last_B = 0, last_L = 0;
+  size_t status_misc_off = (size_t)-1;  // device status word (misc region, floats) or -1: the handle has no GroupNorm
   size_t emb_misc_off = 0;  // conditioning vector [max_batch][emb_E] of the last forward (misc region, floats); emb_E = 0: none
   int emb_E = 0;
   std::shared_ptr<void> keepalive;  // schedule builder (resolves arena/weight offsets for the ops)

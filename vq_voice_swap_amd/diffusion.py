@@ -201,6 +201,9 @@ class Diffusion:
                 x_t = self._step(x_t, eps, a_t_all[i], a_prev_all[i], ts_prev_all[i], noise=nz, sigma_large=sigma_large,
                                  constrain=constrain, cond_fn=cond_fn, seed=seed, clip_offset=clip_offset, step_index=i,
                                  noise_scale=0.0 if last else 1.0)
+        chk = getattr(predictor, "check_status", None)  # range guard of a native predictor: once per sample, not per step
+        if chk is not None:
+            chk()
         return x_t
 
 

@@ -98,7 +98,6 @@ class _NativeModule(nn.Module):
             self._handle.close()
         self._handle = None
         self._handle_key = None
-        self.__dict__.pop("_token_tensors", None)
 
     def _apply(self, fn, *a, **k):
         self.invalidate()
@@ -116,17 +115,28 @@ class _NativeModule(nn.Module):
         raise NotImplementedError
 
     def _weights_token(self):
-        """Changes whenever a parameter or buffer is written in place or replaced (`p.data.copy_`, optimizer steps,
-        `load_from_pretrained`, EMA copies): the device snapshot is rebuilt instead of silently running old weights
-        (the reference reads live parameters on every call)."""
-        ts = self.__dict__.get("_token_tensors")
-        if ts is None:  # the module tree is walked once per handle, not once per forward
-            ts = list(self.parameters()) + list(self.buffers())
-            self.__dict__["_token_tensors"] = ts
+        """Changes whenever a parameter or buffer is written in place through autograd-visible ops (optimizer steps, `p.mul_()`,
+        `load_from_pretrained`, EMA copies -- they bump the tensor's version counter) or REPLACED (`mod.weight = nn.Parameter(..)`,
+        `load_state_dict(assign=True)`): the device snapshot is then rebuilt instead of silently running old weights (the
+        reference reads live parameters on every call).  The module tree is walked on every call, so a replaced tensor is seen.
+        NOT seen: writes through `.data` (`p.data.copy_(..)` does not bump the version counter) -- call `invalidate()` after
+        those."""
         tok = 0
-        for t in ts:
-            tok = (tok * 1000003 + t._version * 8191 + t.data_ptr()) & 0xFFFFFFFFFFFF
+        for t in list(self.parameters()) + list(self.buffers()):
+            tok = (tok * 1000003 + t._version * 8191 + t.data_ptr() + id(t)) & 0xFFFFFFFFFFFF
         return tok
+
+    def check_status(self) -> None:
+        """Range guard (vqvs_model_status): raise if the handle's GroupNorm statistics saw a non-finite value or, in the fp16
+        mode, an activation magnitude that fp16 storage cannot be trusted with.  One device sync: call once per sample."""
+        h = self._handle
+        if h is None:
+            return
+        w = h.status()
+        if w:
+            what = ("non-finite GroupNorm statistics (an activation overflowed the storage type, or the input held NaN/inf)" if w & 1
+                    else "activations beyond 3e4 in the fp16 mode (fp16 overflows at 65504)")
+            raise _native.NativeError(f"range guard: {what}; run this model with set_precision('fp32')")
 
     def handle(self, device: torch.device, B: int, T: int) -> _native.Handle:
         idx = device.index if device.index is not None else torch.cuda.current_device()
