@@ -3,7 +3,7 @@
 import csv, glob, os, sys, collections
 
 NK = int(os.environ.get("NKERNELS", "339"))
-ours = ("conv_mfma_kernel", "gn_prepare_kernel", "in_conv_kernel", "out_conv_kernel", "film_kernel", "time_embed_kernel", "xform_kernel")
+ours = ("conv_ws_kernel", "conv_mfma_kernel", "gn_prepare_kernel", "in_conv_kernel", "out_conv_kernel", "film_kernel", "time_embed_kernel", "xform_kernel")
 per_pass = []
 for d in sys.argv[1:]:
     rows = collections.OrderedDict()

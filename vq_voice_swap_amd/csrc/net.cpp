@@ -784,6 +784,8 @@ int tensor_rows(int Lbase, int lshift) { return shiftL(Lbase, lshift); }
 // The guidance gradients d log p / d activation are O(1e-6 ... 1e-3): in fp16 storage they would sit in or below the
 // subnormal range (6e-5).  The backward schedule is linear in the gradient, so the fp16 mode carries it multiplied by 2^10
 // from the head (gscale) to the last kernel (in_conv_bw), which divides it out again in fp32.  bf16 / fp32 have the range.
+// The caller's guidance scale is NOT part of what the backward schedule carries (it is linear in it): in_conv_bw applies it in fp32,
+// so neither a very large --classifier-scale can overflow fp16 nor a very small one push the gradients into its subnormals.
 float grad_scale(int precision) { return precision == VQVS_PREC_F16 ? 1024.0f : 1.0f; }
 
 int gn_groups(int ch) {  // unet.py:345-349
@@ -1163,7 +1165,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
           a.bias = reinterpret_cast<const float*>(bp->wp(hb));
           a.logits = r.out;
           a.targets = r.backward ? r.labels : nullptr;
-          a.gscale = r.gscale * grad_scale(prec);
+          a.gscale = grad_scale(prec);  // (the caller's scale multiplies the finished gradient in fp32, in_conv_bw: the 2-byte gradient tensors never see it)
           a.dO = bp->act(dO.off);
           a.Cb = OC;
           a.D = D;
@@ -1210,7 +1212,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
           a.out = r.grad_out;
           a.C = base;
           a.T = r.Lbase;
-          a.out_scale = 1.0f / grad_scale(prec);
+          a.out_scale = r.gscale / grad_scale(prec);
           return launch_in_conv_bw(a, r.B, prec, r.st);
         });
         m->cur_phase = 0;
@@ -1346,7 +1348,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
       a.bl = reinterpret_cast<const float*>(bp->wp(bl_off));
       a.logits = r.out;
       a.labels = r.backward ? r.labels : nullptr;
-      a.gscale = r.gscale * grad_scale(prec);
+      a.gscale = grad_scale(prec);  // (the caller's scale multiplies the finished gradient in fp32, in_conv_bw: the 2-byte gradient tensors never see it)
       a.dh = bp->act(dh.off);
       return launch_cls_head(a, r.B, prec, r.st);
     });
@@ -1364,7 +1366,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
         a.out = r.grad_out;
         a.C = base;
         a.T = r.Lbase;
-        a.out_scale = 1.0f / grad_scale(prec);
+        a.out_scale = r.gscale / grad_scale(prec);
         return launch_in_conv_bw(a, r.B, prec, r.st);
       });
     }

@@ -23,6 +23,18 @@ CHANNEL_MULT = (1, 1, 2, 2, 2, 4, 4, 8, 8)
 MIDDLE_DILATIONS = (4, 8, 16, 32)
 
 
+SUPPORTED_BASE_CHANNELS = (32, 64)
+
+
+def check_base_channels(base_channels: int) -> None:
+    """The native schedule is built for the reference's two published widths; the reference itself accepts any
+    `base_channels` (models/unet.py:17-30).  Fail here, with the reason, rather than at handle creation."""
+    if base_channels not in SUPPORTED_BASE_CHANNELS:
+        raise ValueError(f"base_channels={base_channels}: the gfx950 library supports {SUPPORTED_BASE_CHANNELS} "
+                         "(GroupNorm blocks wider than 1024 channels are not built); see INTEGRATION.md")
+
+
+
 def default_precision() -> str:
     return os.environ.get("VQVS_PRECISION", "fp32")
 
@@ -199,6 +211,7 @@ class UNetPredictor(_NativeModule):
         super().__init__()
         if tuple(channel_mult) != CHANNEL_MULT or tuple(middle_dilations) != MIDDLE_DILATIONS or depth_mult != 2:
             raise ValueError("the gfx950 library implements the reference's default UNet topology only")
+        check_base_channels(base_channels)
         self.base_channels = base_channels
         self.channel_mult = tuple(channel_mult)
         self.middle_dilations = tuple(middle_dilations)
@@ -326,6 +339,7 @@ class UNetEncoder(_NativeModule):
         super().__init__()
         if tuple(channel_mult) != CHANNEL_MULT or tuple(out_dilations) or depth_mult != 2:
             raise ValueError("the gfx950 library implements the reference's default UNetEncoder topology only")
+        check_base_channels(base_channels)
         self.base_channels = base_channels
         self.channel_mult = tuple(channel_mult)
         self.depth_mult = depth_mult
