@@ -5,10 +5,39 @@
 //   hipcc -O3 --offload-arch=gfx950 stream_skel.hip -o stream_skel && ./stream_skel
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float gelu7(float v) {
+  const float vc = __builtin_amdgcn_fmed3f(v, -4.0f, 4.0f);
+  const float w = vc * vc;
+  float p = fmaf(-1.301278171e-09f, w, 1.041951057e-07f);
+  p = fmaf(p, w, -3.657111166e-06f);
+  p = fmaf(p, w, 7.485478930e-05f);
+  p = fmaf(p, w, -1.006488756e-03f);
+  p = fmaf(p, w, 9.505392772e-03f);
+  p = fmaf(p, w, -6.588783436e-02f);
+  p = fmaf(p, w, 3.986733897e-01f);
+  return v * fmaf(vc, p, 0.5f);
+}
+__device__ __forceinline__ u32x4 xform8(u32x4 raw, f32x4 s0, f32x4 s1, f32x4 s2, f32x4 s3) {
+  const f16x8 h = __builtin_bit_cast(f16x8, raw);
+  f16x8 o;
+  o[0] = (_Float16)gelu7(fmaf((float)h[0], s0[0], s0[1]));
+  o[1] = (_Float16)gelu7(fmaf((float)h[1], s0[2], s0[3]));
+  o[2] = (_Float16)gelu7(fmaf((float)h[2], s1[0], s1[1]));
+  o[3] = (_Float16)gelu7(fmaf((float)h[3], s1[2], s1[3]));
+  o[4] = (_Float16)gelu7(fmaf((float)h[4], s2[0], s2[1]));
+  o[5] = (_Float16)gelu7(fmaf((float)h[5], s2[2], s2[3]));
+  o[6] = (_Float16)gelu7(fmaf((float)h[6], s3[0], s3[1]));
+  o[7] = (_Float16)gelu7(fmaf((float)h[7], s3[2], s3[3]));
+  return __builtin_bit_cast(u32x4, o);
+}
 
-template <int MODE /*1 loads, 2 stores, 3 both*/, int DEPTH, int C>
+template <int MODE /*1 loads, 2 stores, 3 both*/, int DEPTH, int C, int COMP /*1 producer prologue, 2 consumer MFMAs, 4 weight DMA per step, 8 tile-end statistics + rounding into LDS, 16 wave-private epilogue + store BEHIND the barrier, 32 the PRODUCERS issue the weight DMA, 64 packed-fp32 statistics instead of v_dot2c*/>
 __global__ __launch_bounds__(1024) void k(const char* __restrict__ src, char* __restrict__ dst, int tiles_total) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NCH = C / 32;
@@ -47,14 +76,27 @@ __global__ __launch_bounds__(1024) void k(const char* __restrict__ src, char* __
     for (;;) {
 #pragma unroll
       for (int d = 0; d < DEPTH; ++d) {
+        if (COMP & 32) {  // the weights of the chunk the consumers multiply next step: 24 pieces of 1 KiB over the 8 producer waves
+          typedef __attribute__((address_space(3))) void* lds_ptr;
+          const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(src), 0, 1 << 20, 0x00020000);
+          for (int p = wave - 8; p < 24; p += 8)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(smem + 65536 + p * 1024), 16, (q & 3) * 24576 + p * 1024 + (tid & 63) * 16, 0, 0, 0);
+        }
         if (MODE & 1) {
           if (DEPTH == 3) asm volatile("s_waitcnt vmcnt(4)" : "+v"(a[d][0]), "+v"(a[d][1]));
           if (DEPTH == 2) asm volatile("s_waitcnt vmcnt(2)" : "+v"(a[d][0]), "+v"(a[d][1]));
           if (DEPTH == 4) asm volatile("s_waitcnt vmcnt(6)" : "+v"(a[d][0]), "+v"(a[d][1]));
         }
-        *reinterpret_cast<u32x4*>(smem + (q & 1) * 16384 + dst0) = a[d][0];
-        *reinterpret_cast<u32x4*>(smem + (q & 1) * 16384 + dst0 + 8192) = a[d][1];
+        u32x4 o0 = a[d][0], o1 = a[d][1];
+        if (COMP & 1) {
+          const f32x4 s0 = {1.0f, 0.1f, 0.9f, -0.1f}, s1 = {1.1f, 0.2f, 1.0f, -0.2f}, s2 = {0.7f, 0.07f, 0.63f, -0.07f}, s3 = {1.43f, 0.26f, 1.3f, -0.26f};
+          o0 = xform8(o0, s0, s1, s2, s3);
+          o1 = xform8(o1, s0, s1, s2, s3);
+        }
+        *reinterpret_cast<u32x4*>(smem + (q & 1) * 16384 + dst0) = o0;
+        *reinterpret_cast<u32x4*>(smem + (q & 1) * 16384 + dst0 + 8192) = o1;
         issue(a[d][0], a[d][1]);
+        if (COMP & 32) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // everything but the two loads just issued: the DMA has landed
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (++q == Q) goto done;
@@ -66,9 +108,41 @@ __global__ __launch_bounds__(1024) void k(const char* __restrict__ src, char* __
   } else {
     __builtin_amdgcn_s_barrier();
     int tile = tb;
+    const int lane = tid & 63, wt = wave & 3, wc = wave >> 2, l31 = lane & 31, hh = lane >> 5;
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    int boff[2];
+    const int wr = wc * 64 + l31;
+    for (int ks = 0; ks < 2; ++ks) boff[ks] = 40960 + wr * 64 + (((ks * 2 + hh) ^ ((wr >> 2) & 3)) << 4);
     for (int g = 0; g < Q; ++g) {
       const int c = g % NCH;
-      if ((MODE & 2) && c == NCH - 1) {  // last chunk of a tile: write the tile (rows from LDS, any bytes will do)
+      if ((COMP & 4) && !(COMP & 32)) {  // this step's share of the next chunk's weights: 24 pieces of 1 KiB over 8 waves (L2-resident source)
+        typedef __attribute__((address_space(3))) void* lds_ptr;
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(src), 0, 1 << 20, 0x00020000);
+        for (int p = wave; p < 24; p += 8)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(smem + 65536 + (g & 1) * 0 + p * 1024), 16, (g & 3) * 24576 + p * 1024 + lane * 16, 0, 0, 0);
+      }
+      if (COMP & 2) {
+        const char* const sb = smem + (g & 1) * 16384;
+        int row = wt * 64 + l31;
+        for (int kk = 0; kk < 3; ++kk, row += 1) {
+          const int swz = (row >> 2) & 3;
+          const char* const wk = smem + kk * (128 * 64);
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const int ao = (row & 255) * 64 + (((ks * 2 + hh) ^ swz) << 4);
+            const f16x8 x0 = *reinterpret_cast<const f16x8*>(sb + ao);
+            const f16x8 x1 = *reinterpret_cast<const f16x8*>(sb + ((ao + 2048) & 16383));
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+              const f16x8 bf = *reinterpret_cast<const f16x8*>(wk + boff[ks] + nt * 2048);
+              acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x0, bf, acc[0][nt], 0, 0, 0);
+              acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x1, bf, acc[1][nt], 0, 0, 0);
+            }
+          }
+        }
+      }
+      if ((MODE & 2) && !(COMP & 16) && c == NCH - 1) {  // last chunk of a tile: write the tile (rows from LDS, any bytes will do)
         char* o = dst + (long long)tile * 256 * C * 2;
         constexpr int PIECES = 256 * C * 2 / 16 / 512;
 #pragma unroll
@@ -78,29 +152,111 @@ __global__ __launch_bounds__(1024) void k(const char* __restrict__ src, char* __
         }
         ++tile;
       } else if (c == NCH - 1) ++tile;
+      if ((COMP & 8) && c == NCH - 1) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const h2 ones = {(_Float16)1.0f, (_Float16)1.0f};
+        char* const ob = smem + 32768 + ((wt * 32 + 2 * hh) * 528 + (wc * 64 + l31) * 4) % 30000;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          float s1 = 0.f, s2 = 0.f;
+          float __attribute__((ext_vector_type(2))) p1 = {0.f, 0.f}, p2 = {0.f, 0.f};
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+              const h2 pk = {(_Float16)acc[mt][nt][r], (_Float16)acc[mt][nt][r + 1]};
+              if (COMP & 64) {
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                const f2 v = {acc[mt][nt][r], acc[mt][nt][r + 1]};
+                p1 += v;
+                p2 = __builtin_elementwise_fma(v, v, p2);
+              } else {
+                s1 = __builtin_amdgcn_fdot2(pk, ones, s1, false);
+                s2 = __builtin_amdgcn_fdot2(pk, pk, s2, false);
+              }
+              *reinterpret_cast<h2*>(ob + ((mt * 16 + ((r & 3) >> 1) + 4 * (r >> 2)) * 528 + nt * 128) % 2000) = pk;
+            }
+          if (COMP & 64) { s1 = p1[0] + p1[1]; s2 = p2[0] + p2[1]; }
+          s1 += __shfl_xor(s1, 32);
+          s2 += __shfl_xor(s2, 32);
+          if (hh == 0) reinterpret_cast<float*>(smem + 90000)[(wt * 128 + wc * 64 + nt * 32 + l31) % 1024] = s1 + s2;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.5f;
+      }
+      if ((COMP & 4) && !(COMP & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      if ((COMP & 16) && c == NCH - 1) {
+        // wave-private epilogue: this wave's 64 rows x 64 channels -> (statistics, rounding) -> its own 8 KiB of LDS as row pairs ->
+        // back as whole 128-byte row pieces -> global.  No other wave touches the region: no barrier, only lgkmcnt.
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const h2 ones = {(_Float16)1.0f, (_Float16)1.0f};
+        char* const reg = smem + 32768 + wave * 8448;  // 32 row pairs x (64 ch x 4 B + 8 pad)
+        char* const ob = reg + (2 * hh) * 264 + l31 * 4;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+              const h2 pk = {(_Float16)acc[mt][nt][r], (_Float16)acc[mt][nt][r + 1]};
+              s1 = __builtin_amdgcn_fdot2(pk, ones, s1, false);
+              s2 = __builtin_amdgcn_fdot2(pk, pk, s2, false);
+              *reinterpret_cast<h2*>(ob + (mt * 16 + ((r & 3) >> 1) + 4 * (r >> 2)) * 264 + nt * 128) = pk;
+            }
+          s1 += __shfl_xor(s1, 32);
+          s2 += __shfl_xor(s2, 32);
+          if (hh == 0) reinterpret_cast<float*>(smem + 100352)[(wt * 128 + wc * 64 + nt * 32 + l31) % 1024] = s1 + s2;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.5f;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (MODE & 2) {
+          char* o = dst + (long long)(tile - 1) * 256 * C * 2 + (long long)(wt * 64) * C * 2 + wc * 128;
+          // lane -> (row pair p = lane >> 3 (+8 per iteration), 8-channel piece q = lane & 7): 2 x 16 B of LDS -> two rows x 16 B
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int p = (lane >> 3) + 8 * i, q = lane & 7;
+            const u32x4 lo = *reinterpret_cast<const u32x4*>(reg + p * 264 + q * 32);
+            const u32x4 hi = *reinterpret_cast<const u32x4*>(reg + p * 264 + q * 32 + 16);
+            u32x4 e, od;
+            e[0] = __builtin_amdgcn_perm(lo[1], lo[0], 0x05040100u); e[1] = __builtin_amdgcn_perm(lo[3], lo[2], 0x05040100u);
+            e[2] = __builtin_amdgcn_perm(hi[1], hi[0], 0x05040100u); e[3] = __builtin_amdgcn_perm(hi[3], hi[2], 0x05040100u);
+            od[0] = __builtin_amdgcn_perm(lo[1], lo[0], 0x07060302u); od[1] = __builtin_amdgcn_perm(lo[3], lo[2], 0x07060302u);
+            od[2] = __builtin_amdgcn_perm(hi[1], hi[0], 0x07060302u); od[3] = __builtin_amdgcn_perm(hi[3], hi[2], 0x07060302u);
+            *reinterpret_cast<u32x4*>(o + (long long)(2 * p) * C * 2 + q * 16) = e;
+            *reinterpret_cast<u32x4*>(o + (long long)(2 * p + 1) * C * 2 + q * 16) = od;
+          }
+        }
+      }
+    }
+    if (COMP & 2) {
+      float r = 0.f;
+      for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int q = 0; q < 16; ++q) r += acc[i][j][q];
+      if (r == 1.2345f) dst[tid] = 1;
     }
   }
 }
 
-template <int MODE, int DEPTH, int C>
+template <int MODE, int DEPTH, int C, int COMP = 0>
 void run(const char* s, char* d, long long bytes) {
   const int tiles = (int)(bytes / (256 * C * 2));
-  const int LDS = 80 * 1024;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k<MODE, DEPTH, C>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  const int LDS = 112 * 1024;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k<MODE, DEPTH, C, COMP>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
-  hipLaunchKernelGGL((k<MODE, DEPTH, C>), dim3(256), dim3(1024), LDS, 0, s, d, tiles);
+  hipLaunchKernelGGL((k<MODE, DEPTH, C, COMP>), dim3(256), dim3(1024), LDS, 0, s, d, tiles);
   (void)hipEventRecord(e0);
-  for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((k<MODE, DEPTH, C>), dim3(256), dim3(1024), LDS, 0, s, d, tiles);
+  for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((k<MODE, DEPTH, C, COMP>), dim3(256), dim3(1024), LDS, 0, s, d, tiles);
   (void)hipEventRecord(e1);
   (void)hipEventSynchronize(e1);
   float ms;
   (void)hipEventElapsedTime(&ms, e0, e1);
   const double moved = (double)bytes * ((MODE & 1 ? 1 : 0) + (MODE & 2 ? 1 : 0)) * 5;
-  printf("  C=%3d depth %d %s: %7.3f ms per pass, %5.2f TB/s\n", C, DEPTH, MODE == 1 ? "loads only " : MODE == 2 ? "stores only" : "loads+stores", ms / 5, moved / (ms * 1e-3) / 1e12);
+  printf("  C=%3d depth %d %-12s compute %d: %7.3f ms per pass, %5.2f TB/s\n", C, DEPTH, MODE == 0 ? "no memory" : MODE == 1 ? "loads only" : MODE == 2 ? "stores only" : "loads+stores", COMP, ms / 5, moved / (ms * 1e-3) / 1e12);
 }
 
 int main() {
@@ -108,7 +264,17 @@ int main() {
   char *s, *d;
   (void)hipMalloc(&s, bytes);
   (void)hipMalloc(&d, bytes);
-  (void)hipMemset(s, 1, bytes);
+  {  // random fp16 activations in [-2, 2): constant data would let the chip clock higher than real data does
+    unsigned short* h = (unsigned short*)malloc(bytes);
+    unsigned x = 12345u;
+    for (long long i = 0; i < bytes / 2; ++i) {
+      x = x * 1664525u + 1013904223u;
+      const unsigned mant = (x >> 9) & 0x3ff, ex = 12 + ((x >> 20) % 4), sg = (x >> 31) << 15;
+      h[i] = (unsigned short)(sg | (ex << 10) | mant);
+    }
+    (void)hipMemcpy(s, h, bytes, hipMemcpyHostToDevice);
+    free(h);
+  }
   run<1, 3, 64>(s, d, bytes);
   run<2, 3, 64>(s, d, bytes);
   run<3, 3, 64>(s, d, bytes);
@@ -118,5 +284,26 @@ int main() {
   run<1, 3, 128>(s, d, bytes);
   run<2, 3, 128>(s, d, bytes);
   run<3, 3, 128>(s, d, bytes);
+  printf("with the producers' prologue arithmetic (1) and / or the consumers' MFMA chunk loop (2):\n");
+  run<0, 3, 128, 1>(s, d, bytes);
+  run<0, 3, 128, 2>(s, d, bytes);
+  run<0, 3, 128, 3>(s, d, bytes);
+  run<1, 3, 128, 3>(s, d, bytes);
+  run<2, 3, 128, 3>(s, d, bytes);
+  run<3, 3, 128, 3>(s, d, bytes);
+  run<3, 3, 128, 1>(s, d, bytes);
+  run<3, 3, 128, 2>(s, d, bytes);
+  run<3, 3, 128, 79>(s, d, bytes);
+  run<0, 3, 128, 79>(s, d, bytes);
+  run<3, 3, 128, 47>(s, d, bytes);
+  run<0, 3, 128, 47>(s, d, bytes);
+  run<3, 3, 128, 39>(s, d, bytes);
+  run<3, 3, 128, 23>(s, d, bytes);
+  run<3, 3, 128, 19>(s, d, bytes);
+  run<0, 3, 128, 23>(s, d, bytes);
+  run<3, 3, 128, 7>(s, d, bytes);
+  run<3, 3, 128, 11>(s, d, bytes);
+  run<3, 3, 128, 15>(s, d, bytes);
+  run<0, 3, 128, 15>(s, d, bytes);
   return 0;
 }

@@ -124,7 +124,10 @@ __device__ unsigned long long g_ws_timing[32];
 // once per workgroup instead of once per tile and step -- the per-CU path from L2 is the scarce resource (~11 B / cycle / CU,
 // whether the bytes come from HBM or from L2), and a re-streamed 32-channel weight chunk (3 * CT * 64 B) weighs more on it than
 // the activation chunk it multiplies (16 KiB).
-template <typename T, int WN, bool RES>
+// POST: the tile epilogue (statistics, rounding, the round trip through LDS that turns accumulator lanes into row pieces, the
+// stores) runs BEHIND the barrier that ends the tile's last step, every consumer wave on its own 64 rows and its own LDS region --
+// no cross-wave hand-off, so it overlaps the producers' staging of the next chunk instead of holding them at the barrier.
+template <typename T, int WN, bool RES, bool POST>
 __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
   constexpr int CT = 64 * WN;             // output channels per tile: 2 consumer columns x WN MFMA tiles of 32
   constexpr int ACT_BYTES = 256 * 64;     // 256 staged rows x 32 channels
@@ -137,8 +140,10 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
   constexpr int WS_OFF = RES ? 2 * ACT_BYTES : ACT_BYTES;  // streamed (or identity) weight slot s at WS_OFF + s * WS_STRIDE
   constexpr int WS_STRIDE = RES ? CT * 64 : STAGE;
   constexpr int O_OFF = RES ? 2 * ACT_BYTES + 2 * CT * 64 : 2 * STAGE;
-  constexpr int R_OFF = O_OFF + 128 * OP;  // [4 time quarters][CT][2] partial statistics
-  constexpr int WRES_OFF = R_OFF + 4 * CT * 8;
+  constexpr int RP = WN * 128 + 16;       // POST: pitch of a row PAIR in a wave's private region (WN * 32 channels, a dword each)
+  constexpr int OW = 32 * RP;             // POST: bytes of one wave's region (its 64 rows)
+  constexpr int R_OFF = O_OFF + (POST ? 8 * OW : 128 * OP);  // [tile parity (POST)][4 time quarters][CT][2] partial statistics
+  constexpr int WRES_OFF = R_OFF + (POST ? 2 : 1) * 4 * CT * 8;
   const int SS_OFF = WRES_OFF + (RES ? a.wres_bytes : 0);  // per-clip (scale, shift) tables, a.ss_ring of them
   constexpr int GQ = WsOp<T>::gq;
   typedef typename WsOp<T>::v8 V8;
@@ -330,14 +335,21 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
       const int um = __builtin_amdgcn_readfirstlane((int)r.meta);
       u32x4 o0 = r.a0, o1 = r.a1;
       if ((um & 1) && !(VQVS_WS_EXP & 8)) {
-        const f32x4* const sp = reinterpret_cast<const f32x4*>(smem + r.ssaddr);
-        const f32x4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
+        const f32x4* const sp = reinterpret_cast<const f32x4*>(smem + ((VQVS_WS_EXP & 64) ? 0 : r.ssaddr));
+        f32x4 s0, s1, s2, s3;
+        if (VQVS_WS_EXP & 64) {
+          s0 = f32x4{1.0f, 0.1f, 0.9f, -0.1f}; s1 = f32x4{1.1f, 0.2f, 1.0f, -0.2f}; s2 = f32x4{0.7f, 0.07f, 0.63f, -0.07f}; s3 = f32x4{1.43f, 0.26f, 1.3f, -0.26f};
+        } else {
+          s0 = sp[0]; s1 = sp[1]; s2 = sp[2]; s3 = sp[3];
+        }
         o0 = xform8(r.a0, s0, s1, s2, s3);
         o1 = xform8(r.a1, s0, s1, s2, s3);
       }
       const u32x4 z = {0u, 0u, 0u, 0u};
-      if (!(r.meta & 2u)) o0 = z;
-      if (!(r.meta & 4u)) o1 = z;
+      if (!(VQVS_WS_EXP & 128)) {
+        if (!(r.meta & 2u)) o0 = z;
+        if (!(r.meta & 4u)) o1 = z;
+      }
       *reinterpret_cast<u32x4*>(sb + dst0) = o0;
       *reinterpret_cast<u32x4*>(sb + dst0 + 128 * 64) = o1;
       if (um & 8) {
@@ -387,6 +399,7 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
 #undef WS_PBODY
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the over-issued loads of the tail
     sync_lds();  // the consumers' last step
+    if constexpr (POST) sync_lds();  // (and their barrier before the last tile's statistics are combined)
 #ifdef VQVS_TIMING
     if (lane == 0 && ((int)blockIdx.x & 15) == 3) {
       for (int i = 0; i < 4; ++i) atomicAdd(&g_ws_timing[i], tacc[i]);
@@ -483,6 +496,105 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
       }
     };
 
+    // ---- POST form of the epilogue ----
+    TileCo st_{0, 0, 0};      // tile whose partial statistics wait in R[spar ^ 1] for their combine (one barrier later)
+    bool stats_pending = false;
+    int spar = 0;
+    auto combine_stats = [&]() {
+      int zl = 0;
+      asm volatile("" : "+v"(zl));
+      const int ltid = tid + zl;
+      if (a.stats != nullptr && ltid < CT) {
+        const float2* const red = reinterpret_cast<const float2*>(smem + R_OFF) + (spar ^ 1) * 4 * CT;
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {  // fixed order: deterministic
+          const float2 v = red[g * CT + ltid];
+          t1 += v.x;
+          t2 += v.y;
+        }
+        float2* o = reinterpret_cast<float2*>(a.stats) + ((size_t)st_.b * a.ntiles_stat + st_.tx) * a.Cout + st_.ty * CT + ltid;
+        *o = float2{t1, t2};
+      }
+      stats_pending = false;
+    };
+    auto epilogue_post = [&](const TileCo& tc) {
+      int zl = 0;
+      asm volatile("" : "+v"(zl));
+      const int t0 = tc.tx * a.TTO;
+      const int nvalid = min(a.TTO, a.Lout - t0);
+      const int lim = nvalid - (wt * 64 + 4 * hh) + zl;
+      if (wt * 64 + 64 > nvalid) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if (mt * 32 + (r & 3) + 8 * (r >> 2) >= lim) acc[mt][nt][r] = 0.f;
+      }
+      char* const reg = smem + O_OFF + wave * OW;
+      char* const ob = reg + (2 * hh) * RP + (l31 + zl) * 4;
+#pragma unroll
+      for (int nt = 0; nt < WN; ++nt) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            char* const o0 = ob + (mt * 16 + ((r & 3) >> 1) + 4 * (r >> 2)) * RP + nt * 128;
+            if constexpr (WsOp<T>::one == 0x3C00) {
+              typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+              const h2 ones = {(_Float16)1.0f, (_Float16)1.0f};
+              const h2 pk = {(_Float16)acc[mt][nt][r], (_Float16)acc[mt][nt][r + 1]};
+              s1 = __builtin_amdgcn_fdot2(pk, ones, s1, false);
+              s2 = __builtin_amdgcn_fdot2(pk, pk, s2, false);
+              *reinterpret_cast<h2*>(o0) = pk;
+            } else {
+              typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+              const b2 pk = {(__bf16)acc[mt][nt][r], (__bf16)acc[mt][nt][r + 1]};
+              const float v0 = (float)pk[0], v1 = (float)pk[1];
+              s1 += v0 + v1;
+              s2 = fmaf(v0, v0, fmaf(v1, v1, s2));
+              *reinterpret_cast<b2*>(o0) = pk;
+            }
+          }
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (hh == 0) reinterpret_cast<float2*>(smem + R_OFF)[spar * 4 * CT + wt * CT + wc * (WN * 32) + nt * 32 + l31 + zl] = float2{s1, s2};
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's own region: no barrier needed
+      // own region -> global: a lane takes 8 channels of a row pair, separates the rows, stores 16 B of each
+      constexpr int OPW = 4 * WN;         // 8-channel pieces per row
+      constexpr int PSTEP = 64 / OPW;     // row pairs per pass
+      const int lz = lane + zl;
+      const int p0 = lz / OPW, oc = lz - p0 * OPW;
+      T* const gdst = outp + ((size_t)tc.b * a.Lout + t0 + wt * 64 + 2 * p0) * a.Cout + tc.ty * CT + wc * (WN * 32) + oc * 8;
+#pragma unroll
+      for (int i = 0; i < 32 / PSTEP; ++i) {
+        const int row = wt * 64 + 2 * (p0 + i * PSTEP);
+        if (row < nvalid) {
+          const u32x4 lo = *reinterpret_cast<const u32x4*>(reg + (p0 + i * PSTEP) * RP + oc * 32);
+          const u32x4 hi = *reinterpret_cast<const u32x4*>(reg + (p0 + i * PSTEP) * RP + oc * 32 + 16);
+          u32x4 e, o;
+          e[0] = __builtin_amdgcn_perm(lo[1], lo[0], 0x05040100u);
+          e[1] = __builtin_amdgcn_perm(lo[3], lo[2], 0x05040100u);
+          e[2] = __builtin_amdgcn_perm(hi[1], hi[0], 0x05040100u);
+          e[3] = __builtin_amdgcn_perm(hi[3], hi[2], 0x05040100u);
+          o[0] = __builtin_amdgcn_perm(lo[1], lo[0], 0x07060302u);
+          o[1] = __builtin_amdgcn_perm(lo[3], lo[2], 0x07060302u);
+          o[2] = __builtin_amdgcn_perm(hi[1], hi[0], 0x07060302u);
+          o[3] = __builtin_amdgcn_perm(hi[3], hi[2], 0x07060302u);
+          T* const g = gdst + (size_t)(2 * i * PSTEP) * a.Cout;
+          *reinterpret_cast<u32x4*>(g) = e;
+          if (row + 1 < nvalid) *reinterpret_cast<u32x4*>(g + a.Cout) = o;
+        }
+      }
+      st_ = tc;
+      spar ^= 1;
+      stats_pending = true;
+    };
+
     // chunk cursors: `ct` / `cci` = tile and chunk of the current step; the DMA cursor (tile `nt_`, segment `dseg`, chunk `dch`) runs
     // one chunk ahead; its segment's fields are fetched when the segment is entered, the following segment's are prefetched
     TileCo ct = first, nt_ = first;
@@ -529,11 +641,16 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
     dma_advance();
     float bj[WN];
     int bias_ty = -1;
+    int aoff[3][2], aoff_d = -1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // first chunk's (or all resident) weights have landed
     sync_all();
     WS_TMARK(4)
     for (int g = 0; g < Q; ++g) {
       if (cci == 0) {  // first chunk of a tile
+        if ((VQVS_WS_EXP & 256) && pending) {
+          store_tile();
+          pending = false;
+        }
         if (ct.ty != bias_ty) {  // (one channel tile per launch at Cout <= 128: loaded once)
           bias_ty = ct.ty;
 #pragma unroll
@@ -556,31 +673,42 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
       WS_TMARK(1)
       const char* const sb = smem + (g & 1) * ACT_STRIDE;
       const char* const sw = smem + wb;
-      int row = wt * 64 + l31;  // LDS row of output row l31 (+32) of this wave for tap 0; +d per tap
       {
         // (an identity-segment chunk is a 1-tap chunk whose weights are the identity block the producers wrote: rows of the other
         //  channel tiles are zero, so every wave runs the same code on every chunk)
-        const int nk = (VQVS_WS_EXP & 16) ? 0 : (ntaps == 3 ? 3 : 1);
-        for (int k = 0; k < nk; ++k, row += d) {
-          const int swz = (row >> 2) & 3;
-          const char* const wk = sw + k * (CT * 64);
+        if (d != aoff_d) {  // A-fragment offsets of the three taps (swizzled rows: not additive in the tap), rebuilt when the dilation changes
+          aoff_d = d;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const int row = wt * 64 + l31 + k * d;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) aoff[k][ks] = row * 64 + (((ks * 2 + hh) ^ ((row >> 2) & 3)) << 4);
+          }
+        }
+        auto tap = [&](int k) {
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
-            const int ao = row * 64 + (((ks * 2 + hh) ^ swz) << 4);
-            const V8 a0 = *reinterpret_cast<const V8*>(sb + ao);
-            const V8 a1 = *reinterpret_cast<const V8*>(sb + ao + 32 * 64);
+            const V8 a0 = *reinterpret_cast<const V8*>(sb + aoff[k][ks]);
+            const V8 a1 = *reinterpret_cast<const V8*>(sb + aoff[k][ks] + 32 * 64);
 #pragma unroll
             for (int nt = 0; nt < WN; ++nt) {
-              const V8 bf = *reinterpret_cast<const V8*>(wk + boff[ks] + nt * 32 * 64);
+              const V8 bf = *reinterpret_cast<const V8*>(sw + k * (CT * 64) + boff[ks] + nt * 32 * 64);
               acc[0][nt] = ws_mfma(a0, bf, acc[0][nt]);
               acc[1][nt] = ws_mfma(a1, bf, acc[1][nt]);
             }
+          }
+        };
+        if (!(VQVS_WS_EXP & 16)) {
+          tap(0);
+          if (ntaps == 3) {
+            tap(1);
+            tap(2);
           }
         }
       }
       WS_TMARK(2)
       // last chunk of the tile: statistics + rounding + out-tile
-      if (cci == n - 1 && (VQVS_WS_EXP & 32)) {
+      if (!POST && cci == n - 1 && (VQVS_WS_EXP & 32)) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -588,7 +716,7 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
         pt_ = ct;
         pending = true;
       }
-      if (cci == n - 1 && !(VQVS_WS_EXP & 32)) {
+      if (!POST && cci == n - 1 && !(VQVS_WS_EXP & 32)) {
         int zl = 0;
         asm volatile("" : "+v"(zl));
         const int t0 = ct.tx * a.TTO;
@@ -638,6 +766,8 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
         pending = true;
       }
       WS_TMARK(3)
+      const bool tile_done = cci == n - 1;
+      const TileCo done_tile = ct;
       if (++cci == n) {
         cci = 0;
         next_tile(ct);
@@ -658,9 +788,17 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
       } else {
         sync_all();
       }
+      if constexpr (POST) {
+        if (stats_pending) combine_stats();       // (the previous tile's partials: their barrier has passed)
+        if (tile_done) epilogue_post(done_tile);  // overlaps the producers' next chunk
+      }
       WS_TMARK(4)
     }
     if (pending) store_tile();
+    if constexpr (POST) {
+      sync_all();  // (the last tile's partial statistics; the producers match this barrier)
+      if (stats_pending) combine_stats();
+    }
 #ifdef VQVS_TIMING
     WS_TMARK(0)
     if (lane == 0 && ((int)blockIdx.x & 15) == 3) {
@@ -693,29 +831,33 @@ int ws_num_cus() {
 }
 
 template <int WN>
-constexpr int ws_fixed_lds(bool res) {  // LDS bytes besides resident weights
+constexpr int ws_fixed_lds(bool res, bool post = false) {  // LDS bytes besides resident weights
   constexpr int CT = 64 * WN;
-  return (res ? 2 * 256 * 64 + 2 * CT * 64 : 2 * (256 * 64 + 3 * CT * 64)) + 128 * (CT * 4 + 16) + 4 * CT * 8;
+  return (res ? 2 * 256 * 64 + 2 * CT * 64 : 2 * (256 * 64 + 3 * CT * 64)) + (post ? 8 * 32 * (WN * 128 + 16) + 2 * 4 * CT * 8 : 128 * (CT * 4 + 16) + 4 * CT * 8);
 }
 constexpr int WS_LDS_MAX = 160 * 1024;
 
-template <typename T, int WN, bool RES>
+template <typename T, int WN, bool RES, bool POST>
 int ws_launch(const WsArgs& w, hipStream_t st) {
-  const int lds = ws_fixed_lds<WN>(RES) + (RES ? w.wres_bytes : 0) + w.ss_ring * w.ss_bytes;
+  const int lds = ws_fixed_lds<WN>(RES, POST) + (RES ? w.wres_bytes : 0) + w.ss_ring * w.ss_bytes;
   static bool attr_done = false;
   if (!attr_done) {
-    VQVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<T, WN, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_MAX));
+    VQVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<T, WN, RES, POST>), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_MAX));
     attr_done = true;
   }
   const int grid = w.ntiles < ws_num_cus() ? w.ntiles : ws_num_cus();
-  hipLaunchKernelGGL((conv_ws_kernel<T, WN, RES>), dim3(grid), dim3(1024), lds, st, w);
+  hipLaunchKernelGGL((conv_ws_kernel<T, WN, RES, POST>), dim3(grid), dim3(1024), lds, st, w);
   VQVS_HIP(hipGetLastError());
   return 0;
 }
 template <typename T>
-int ws_launch_t(const WsArgs& w, int CT, bool res, hipStream_t st) {
-  if (CT == 128) return res ? ws_launch<T, 2, true>(w, st) : ws_launch<T, 2, false>(w, st);
-  return res ? ws_launch<T, 1, true>(w, st) : ws_launch<T, 1, false>(w, st);
+int ws_launch_t(const WsArgs& w, int CT, bool res, bool post, hipStream_t st) {
+  if (CT == 128) {
+    if (post) return res ? ws_launch<T, 2, true, true>(w, st) : ws_launch<T, 2, false, true>(w, st);
+    return res ? ws_launch<T, 2, true, false>(w, st) : ws_launch<T, 2, false, false>(w, st);
+  }
+  if (post) return res ? ws_launch<T, 1, true, true>(w, st) : ws_launch<T, 1, false, true>(w, st);
+  return res ? ws_launch<T, 1, true, false>(w, st) : ws_launch<T, 1, false, false>(w, st);
 }
 
 }  // namespace
@@ -799,8 +941,13 @@ int launch_conv_ws(const ConvArgs& a, int B, int precision, hipStream_t st) {
   w.ss_ring = (long long)w.ntx * w.nty * n >= 4 ? 2 : 4;
   const int ss_total = w.ss_ring * w.ss_bytes;
   if ((CT == 128 ? ws_fixed_lds<2>(false) : ws_fixed_lds<1>(false)) + ss_total > WS_LDS_MAX) return 0;
-  const bool res = res_env && w.nty == 1 && (CT == 128 ? ws_fixed_lds<2>(true) : ws_fixed_lds<1>(true)) + w.wres_bytes + ss_total <= WS_LDS_MAX;
-  const int rc = precision == 2 ? ws_launch_t<half_t>(w, CT, res, st) : ws_launch_t<bf16_t>(w, CT, res, st);
+  // post-barrier, wave-private epilogue (measured SLOWER: op 64x3->64 at L = 64000 0.263 -> 0.292 ms; kept for A/B): 1 = the
+  // 64-channel tiles, 2 = every launch, 0 (default) = none
+  static const int post_env = getenv("VQVS_WS_POST") ? atoi(getenv("VQVS_WS_POST")) : 0;
+  const bool post = post_env == 2 || (post_env == 1 && CT == 64);
+  if ((CT == 128 ? ws_fixed_lds<2>(false, post) : ws_fixed_lds<1>(false, post)) + ss_total > WS_LDS_MAX) return 0;
+  const bool res = res_env && w.nty == 1 && (CT == 128 ? ws_fixed_lds<2>(true, post) : ws_fixed_lds<1>(true, post)) + w.wres_bytes + ss_total <= WS_LDS_MAX;
+  const int rc = precision == 2 ? ws_launch_t<half_t>(w, CT, res, post, st) : ws_launch_t<bf16_t>(w, CT, res, post, st);
   return rc < 0 ? rc : 1;
 }
 
