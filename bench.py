@@ -25,6 +25,7 @@ Rank 0 prints ONE JSON line.  Extra objects:
                  sample of the same workload, extrapolated to 50 steps.  Reported baseline, not the target.
 """
 import argparse
+import csv
 import json
 import os
 import sys
@@ -200,9 +201,9 @@ def main():
         assert out is not None and out.shape == (n_total, 1, a.T) and bool(torch.isfinite(out).all())
 
     # ---- live per-kernel timing of one forward (hipEvents on the launch stream), rank 0 ----
-    roof = None
-    extra = {}
-    if rank == 0:
+    def kernel_roofline(prec):
+        """Per-kind kernel times of one forward in mode `prec` (hipEvents recorded by the library on its launch stream, mean of 3
+        forwards) and the roofline object of the convolution launches."""
         h = model.predictor.handle(dev, end - begin, a.T)
         B = end - begin
         x = inputs[0]
@@ -222,30 +223,47 @@ def main():
             per_kind[kind]["flops"] += fl
             per_kind[kind]["launches"] += 1
         h.set_profiling(False)
-        # HBM traffic of the same launches from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE are
-        # collected in separate --pmc runs; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950)
-        traffic = None
-        pmc_name = f"r03_pmc_traffic_per_op_unet64_{a.precision}.csv"  # tools/measure.sh, one file per precision mode
+        # HBM traffic and MFMA-busy fraction of the same launches from the committed rocprofv3 PMC passes of the same mode
+        # (tools/measure.sh: every counter set in its own --pmc run; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for
+        # gfx950; SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the 1024 SIMDs, GRBM_GUI_ACTIVE cycles summed over the 8 XCDs)
+        traffic = mfma_busy = None
+        convs = ("conv_ws_kernel", "conv_mfma_kernel")
+        pmc_name = f"r03_pmc_traffic_per_op_unet64_{prec}.csv"
         pmc = os.path.join(ROOT, "profiles", pmc_name)
-        if a.model == "unet64" and B == 64 and a.T == 64000 and os.path.exists(pmc):
-            import csv
-
-            rows = [r for r in csv.DictReader(open(pmc)) if r["kernel"] in ("conv_ws_kernel", "conv_mfma_kernel")]
+        full = a.model == "unet64" and B == 64 and a.T == 64000
+        if full and os.path.exists(pmc):
+            rows = [r for r in csv.DictReader(open(pmc)) if r["kernel"] in convs]
             if rows:
                 traffic = (sum(float(r["FETCH_SIZE"]) for r in rows) * 2 + sum(float(r["WRITE_SIZE"]) for r in rows)) * 1024 / len(rows)
+        pmc2_name = f"r03_pmc_per_op_unet64_{prec}.csv"
+        pmc2 = os.path.join(ROOT, "profiles", pmc2_name)
+        if full and os.path.exists(pmc2):
+            rows = [r for r in csv.DictReader(open(pmc2)) if r["kernel"] in convs]
+            if rows and "SQ_VALU_MFMA_BUSY_CYCLES" in rows[0]:
+                mfma_busy = sum(float(r["SQ_VALU_MFMA_BUSY_CYCLES"]) for r in rows) / (sum(float(r["GRBM_GUI_ACTIVE"]) for r in rows) / 8 * 1024)
         conv = per_kind["conv"]
-        fwd_ms = sum(d["ms"] for d in per_kind.values())
         ach = conv["bytes"] / (conv["ms"] * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None if traffic is None else round(traffic),
+                "mfma_busy": None if mfma_busy is None else round(mfma_busy, 4),
                 "traffic_note": f"HBM bytes per launch from profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate "
                                 "passes of the same mode, FETCH_SIZE x2 on gfx950); algorithmic bytes per launch = "
-                                "algorithmic_bytes_per_forward / launches_per_forward",
-                "kernel": "fused convolution launches: conv_ws_kernel (wave-specialised, persistent) + conv_mfma_kernel (resized / fp32 / odd shapes)",
+                                f"algorithmic_bytes_per_forward / launches_per_forward; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 "
+                                f"* 1024 SIMDs) over the same launches, from profiles/{pmc2_name}",
+                "kernel": "fused convolution launches: conv_ws_kernel (wave-specialised, persistent: 2-byte modes, same-resolution "
+                          "segments) + conv_mfma_kernel (resized segments, fp32 mode)",
                 "launches_per_forward": conv["launches"],
                 "avg_launch_us": round(conv["ms"] * 1e3 / conv["launches"], 2),
                 "algorithmic_bytes_per_forward": conv["bytes"],
                 "mfma_tflops": round(conv["flops"] / (conv["ms"] * 1e-3) / 1e12, 1)}
+        return h, per_kind, roof
+
+    roof = None
+    extra = {}
+    if rank == 0:
+        h, per_kind, roof = kernel_roofline(a.precision)
+        B = end - begin
+        fwd_ms = sum(d["ms"] for d in per_kind.values())
         model_bytes = h.model_bytes(B, a.T)
         extra = {
             "forward_ms_event_sum": round(fwd_ms, 3),
@@ -280,8 +298,10 @@ def main():
             t1 = time.perf_counter()
             model.diffusion.ddpm_sample(x_w, model.predictor, a.sample_steps, constrain=True, schedule=tmap, seed=seed, clip_offset=begin)
             torch.cuda.synchronize()
-            others.append({"dtype": prec, "value": round((end - begin) / (time.perf_counter() - t1), 3), "unit": "clips/s", "steps": 1,
-                           "note": notes[prec]})
+            rate = round((end - begin) / (time.perf_counter() - t1), 3)
+            _h, pk, roof_o = kernel_roofline(prec)
+            others.append({"dtype": prec, "value": rate, "unit": "clips/s", "steps": 1, "note": notes[prec], "roofline": roof_o,
+                           "forward_ms_event_sum": round(sum(d["ms"] for d in pk.values()), 3)})
         model.set_precision(a.precision)
 
     if rank == 0:

@@ -20,6 +20,16 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
   timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o pmc -- python $GRAFT_REPO_ROOT/tools/profile_ops.py --precision $PREC --reps 1 > /tmp/pmc_$c.log 2>&1
 done
-NKERNELS=$(python -c "print(open('$OUT/ops_unet64_$PREC.txt').read().split(' kernels')[0].split()[-1])") python $GRAFT_REPO_ROOT/tools/pmc_per_op.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE > $OUT/pmc_traffic_per_op_unet64_$PREC.csv
+NK=$(python -c "print(open('$OUT/ops_unet64_$PREC.txt').read().split(' kernels')[0].split()[-1])")
+NKERNELS=$NK python $GRAFT_REPO_ROOT/tools/pmc_per_op.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE > $OUT/pmc_traffic_per_op_unet64_$PREC.csv
 head -3 $OUT/pmc_traffic_per_op_unet64_$PREC.csv
+# issue-side counters per op (MFMA busy cycles, VALU / SALU / LDS instruction counts, LDS bank conflicts, wait cycles), two more passes
+i=0
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA"; do
+  i=$((i+1)); rm -rf /tmp/pmc_s$i
+  timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc_s$i -o pmc -- python $GRAFT_REPO_ROOT/tools/profile_ops.py --precision $PREC --reps 1 > /tmp/pmc_s$i.log 2>&1 || tail -3 /tmp/pmc_s$i.log
+done
+NKERNELS=$NK python $GRAFT_REPO_ROOT/tools/pmc_per_op.py /tmp/pmc_s1 /tmp/pmc_s2 > $OUT/pmc_per_op_unet64_$PREC.csv
+head -3 $OUT/pmc_per_op_unet64_$PREC.csv
 fi
