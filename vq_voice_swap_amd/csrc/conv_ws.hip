@@ -72,14 +72,16 @@ __device__ __forceinline__ float ws_gelu(float v) {
 // the segment they are in -- and, prefetched, the one that follows -- in scalar registers; the per-chunk quantities are those
 // plus a multiple of the chunk index, so a step costs a handful of scalar adds and no argument loads.
 struct WsSeg {
-  const void* src;   // [B][Lout][Csrc] of T
+  const void* src;   // [B][Lsrc][Csrc] of T
   const float2* ss;  // (scale, shift) rows [B][ss_stride], or nullptr = raw (no prologue)
   int Csrc;
-  int clip_bytes;    // Lout * Csrc * sizeof(T): bytes of one clip's rows
+  int clip_bytes;    // Lsrc * Csrc * sizeof(T): bytes of one clip's rows (< 2^29)
   int c0;            // first source channel (identity segment: relative to the output channel tile)
   int nch;           // chunks of 32 channels
   int ntaps;         // 3, 1, or 0 = identity segment (weights = the identity block, written by the producers)
   int dil;           // dilation of a 3-tap segment, else 0: LDS row 0 holds time t0 - dil
+  int rsz;           // RESIZE_*: staged row t is source row t (NONE), t >> 1 (UP2: nearest, unet.py:304-305), or the mean of source
+                     // rows 2t and 2t + 1 AFTER the prologue (AVG2: avg_pool1d(2), unet.py:300-303)
   int ss_stride, ss_c0;
   int ss_lds;        // byte offset of this segment's (scale, shift) pairs in the per-clip LDS table
   int wbase, wstep;  // byte offset of chunk 0's packed weights [tap][Cout][32], bytes per chunk
@@ -124,10 +126,10 @@ __device__ unsigned long long g_ws_timing[32];
 // once per workgroup instead of once per tile and step -- the per-CU path from L2 is the scarce resource (~11 B / cycle / CU,
 // whether the bytes come from HBM or from L2), and a re-streamed 32-channel weight chunk (3 * CT * 64 B) weighs more on it than
 // the activation chunk it multiplies (16 KiB).
-// POST: the tile epilogue (statistics, rounding, the round trip through LDS that turns accumulator lanes into row pieces, the
-// stores) runs BEHIND the barrier that ends the tile's last step, every consumer wave on its own 64 rows and its own LDS region --
-// no cross-wave hand-off, so it overlaps the producers' staging of the next chunk instead of holding them at the barrier.
-template <typename T, int WN, bool RES, bool POST>
+// AVG: the launch has an avg-pooled segment (down-sampling blocks, unet.py:297-303): EVERY chunk then issues four loads per
+// thread (two source rows per staged row; the other segments' second pair is an out-of-range dummy that never reaches memory),
+// so that "the oldest chunk has landed" stays one counted wait.
+template <typename T, int WN, bool RES, bool AVG>
 __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
   constexpr int CT = 64 * WN;             // output channels per tile: 2 consumer columns x WN MFMA tiles of 32
   constexpr int ACT_BYTES = 256 * 64;     // 256 staged rows x 32 channels
@@ -140,10 +142,8 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
   constexpr int WS_OFF = RES ? 2 * ACT_BYTES : ACT_BYTES;  // streamed (or identity) weight slot s at WS_OFF + s * WS_STRIDE
   constexpr int WS_STRIDE = RES ? CT * 64 : STAGE;
   constexpr int O_OFF = RES ? 2 * ACT_BYTES + 2 * CT * 64 : 2 * STAGE;
-  constexpr int RP = WN * 128 + 16;       // POST: pitch of a row PAIR in a wave's private region (WN * 32 channels, a dword each)
-  constexpr int OW = 32 * RP;             // POST: bytes of one wave's region (its 64 rows)
-  constexpr int R_OFF = O_OFF + (POST ? 8 * OW : 128 * OP);  // [tile parity (POST)][4 time quarters][CT][2] partial statistics
-  constexpr int WRES_OFF = R_OFF + (POST ? 2 : 1) * 4 * CT * 8;
+  constexpr int R_OFF = O_OFF + 128 * OP;  // [4 time quarters][CT][2] partial statistics
+  constexpr int WRES_OFF = R_OFF + 4 * CT * 8;
   const int SS_OFF = WRES_OFF + (RES ? a.wres_bytes : 0);  // per-clip (scale, shift) tables, a.ss_ring of them
   constexpr int GQ = WsOp<T>::gq;
   typedef typename WsOp<T>::v8 V8;
@@ -204,14 +204,16 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
     const int dst0 = r0 * 64 + ((oct ^ ((r0 >> 2) & 3)) << 4);
     struct Raw {
       u32x4 a0, a1;
+      u32x4 b0, b1;   // AVG: the second source row of each staged row
       unsigned meta;  // bit 0: prologue, bit 1 / 2: row 0 / 1 inside the clip (outside: the convolution's zero padding),
-                      // bit 3: identity segment, bits 8..: its chunk index
+                      // bit 3: identity segment, bit 4: avg-pooled segment, bits 8..: the identity segment's chunk index
       int ssaddr;     // LDS byte address of this thread's eight (scale, shift) pairs
     };
     Raw R0, R1, R2;
     struct Prep {  // everything the two loads of a chunk need
       i32x4 rs;
       int off0, off1, ssaddr;
+      int db;  // AVG: byte distance to the second source row (avg-pooled segment), or 2^30 = out of range (any other segment)
       unsigned meta;
     };
     // load cursor: tile `lt`, segment `lseg`, chunk `lch` of the next loads; `cur` = their parameters (updated incrementally inside
@@ -221,15 +223,15 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
     struct SegF {
       const void* src;
       const float2* ss;
-      int Csrc, clip_bytes, c0, nch, ntaps, dil, ss_lds;
+      int Csrc, clip_bytes, c0, nch, ntaps, dil, rsz, ss_lds;
     };
     auto fetch = [&](int sg) -> SegF {  // (one batch of scalar loads from the argument block, issued a segment ahead of its use)
       const WsSeg& g = a.seg[sg];
-      return SegF{g.src, g.ss, g.Csrc, g.clip_bytes, g.c0, g.nch, g.ntaps, g.dil, g.ss_lds};
+      return SegF{g.src, g.ss, g.Csrc, g.clip_bytes, g.c0, g.nch, g.ntaps, g.dil, g.rsz, g.ss_lds};
     };
     SegF nx = fetch(0);
     Prep cur;
-    int cur_xf = 0, cur_id = 0, cur_idch = 0;  // (wave-uniform parts of meta, kept scalar)
+    int cur_xf = 0, cur_id = 0, cur_idch = 0, cur_avg = 0;  // (wave-uniform parts of meta, kept scalar)
     int ss_clip = -1;  // clip whose (scale, shift) table was written last
     unsigned cur_valid = 0;
     auto refresh_ss = [&]() {
@@ -254,8 +256,11 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
       cur.rs[2] = f.clip_bytes;
       cur.rs[3] = 0x00020000;
       const int tm0 = lt.tx * a.TTO - f.dil + r0, tm1 = tm0 + 128;  // time of this thread's two rows
-      cur.off0 = (tm0 * f.Csrc + f.c0 + (f.ntaps == 0 ? lt.ty * CT : 0) + oct * 8) * 2;
-      cur.off1 = cur.off0 + 256 * f.Csrc;
+      const int sr0 = f.rsz == RESIZE_UP2 ? (tm0 >> 1) : (f.rsz == RESIZE_AVG2 ? 2 * tm0 : tm0);  // (first) source row of row 0
+      cur.off0 = (sr0 * f.Csrc + f.c0 + (f.ntaps == 0 ? lt.ty * CT : 0) + oct * 8) * 2;
+      cur.off1 = cur.off0 + (f.rsz == RESIZE_UP2 ? 128 : (f.rsz == RESIZE_AVG2 ? 512 : 256)) * f.Csrc;
+      cur.db = f.rsz == RESIZE_AVG2 ? 2 * f.Csrc : 0x40000000;
+      cur_avg = f.rsz == RESIZE_AVG2 ? 1 : 0;
       if (__builtin_expect(lseg == 0 && lt.b != ss_clip, 0)) {
         ss_clip = lt.b;
         refresh_ss();
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
     sync_lds();  // (the first clip's (scale, shift) table is visible to every producer wave; the consumers match this barrier)
     auto prepare = [&]() -> Prep {
       Prep pr = cur;
-      pr.meta = cur_valid | (unsigned)(cur_xf | (cur_id << 3) | (cur_idch << 8));
+      pr.meta = cur_valid | (unsigned)(cur_xf | (cur_id << 3) | (cur_avg << 4) | (cur_idch << 8));
       if (++issued < Q) {  // (past the end the last chunk is simply loaded again and never staged)
         if (++lch == lnch) {
           lch = 0;
@@ -292,13 +297,14 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
     };
     // The loads are inline assembly on purpose: hipcc's own wait insertion drains the whole queue (vmcnt(0)) at the top of the
     // rotating loop, which would serialise every third step behind loads issued a moment earlier.  Each chunk issues exactly two
-    // loads (this thread's two activation rows), so "this chunk has landed, the two younger ones may still be in flight" is
-    // vmcnt(4), stated in acquire().
+    // loads (this thread's two activation rows; four with AVG), so "this chunk has landed, the two younger ones may still be in
+    // flight" is vmcnt(4) (vmcnt(8)), stated in acquire().
     auto issue = [&](Raw& r, const Prep& pr) {
       r.meta = pr.meta;
       r.ssaddr = pr.ssaddr;
       if (VQVS_WS_EXP & 1) {
         asm volatile("" : "=v"(r.a0), "=v"(r.a1));  // (opaque garbage, so that nothing downstream folds away)
+        if constexpr (AVG) asm volatile("" : "=v"(r.b0), "=v"(r.b1));
         return;
       }
       // (the descriptor is wave-uniform by construction; say so, or the compiler may hand the assembly a VGPR copy of it when it
@@ -306,16 +312,31 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
       i32x4 rs;
 #pragma unroll
       for (int i = 0; i < 4; ++i) rs[i] = __builtin_amdgcn_readfirstlane(pr.rs[i]);
-      asm volatile(
-          "s_nop 4\n\t"
-          "buffer_load_dwordx4 %0, %2, %4, 0 offen\n\t"
-          "buffer_load_dwordx4 %1, %3, %4, 0 offen"
-          : "=&v"(r.a0), "=&v"(r.a1)
-          : "v"(pr.off0), "v"(pr.off1), "s"(rs));
+      if constexpr (AVG) {
+        const int ob0 = pr.off0 + pr.db, ob1 = pr.off1 + pr.db;
+        asm volatile(
+            "s_nop 4\n\t"
+            "buffer_load_dwordx4 %0, %4, %8, 0 offen\n\t"
+            "buffer_load_dwordx4 %1, %5, %8, 0 offen\n\t"
+            "buffer_load_dwordx4 %2, %6, %8, 0 offen\n\t"
+            "buffer_load_dwordx4 %3, %7, %8, 0 offen"
+            : "=&v"(r.a0), "=&v"(r.b0), "=&v"(r.a1), "=&v"(r.b1)
+            : "v"(pr.off0), "v"(ob0), "v"(pr.off1), "v"(ob1), "s"(rs));
+      } else {
+        asm volatile(
+            "s_nop 4\n\t"
+            "buffer_load_dwordx4 %0, %2, %4, 0 offen\n\t"
+            "buffer_load_dwordx4 %1, %3, %4, 0 offen"
+            : "=&v"(r.a0), "=&v"(r.a1)
+            : "v"(pr.off0), "v"(pr.off1), "s"(rs));
+      }
     };
     auto acquire = [&](Raw& r) {  // the oldest chunk in flight has landed; nothing that reads it may be scheduled above this
       if (VQVS_WS_EXP & 1) return;
-      asm volatile("s_waitcnt vmcnt(4)" : "+v"(r.a0), "+v"(r.a1));
+      if constexpr (AVG)
+        asm volatile("s_waitcnt vmcnt(8)" : "+v"(r.a0), "+v"(r.a1), "+v"(r.b0), "+v"(r.b1));
+      else
+        asm volatile("s_waitcnt vmcnt(4)" : "+v"(r.a0), "+v"(r.a1));
     };
     auto xform8 = [&](u32x4 raw, const f32x4& s0, const f32x4& s1, const f32x4& s2, const f32x4& s3) -> u32x4 {
       const V8 h = __builtin_bit_cast(V8, raw);
@@ -330,6 +351,23 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
       o[7] = (T)ws_gelu<GQ>(fmaf((float)h[7], s3[2], s3[3]));
       return __builtin_bit_cast(u32x4, o);
     };
+    // avg-pooled rows: mean of the two TRANSFORMED source rows, one rounding (the order of conv_mfma.hip's avg path)
+    auto xform8_avg = [&](u32x4 ra, u32x4 rb, const f32x4& s0, const f32x4& s1, const f32x4& s2, const f32x4& s3) -> u32x4 {
+      const V8 h = __builtin_bit_cast(V8, ra), k = __builtin_bit_cast(V8, rb);
+      V8 o;
+#define WS_AVG1(i, sc, sh) o[i] = (T)((ws_gelu<GQ>(fmaf((float)h[i], sc, sh)) + ws_gelu<GQ>(fmaf((float)k[i], sc, sh))) * 0.5f);
+      WS_AVG1(0, s0[0], s0[1]) WS_AVG1(1, s0[2], s0[3]) WS_AVG1(2, s1[0], s1[1]) WS_AVG1(3, s1[2], s1[3])
+      WS_AVG1(4, s2[0], s2[1]) WS_AVG1(5, s2[2], s2[3]) WS_AVG1(6, s3[0], s3[1]) WS_AVG1(7, s3[2], s3[3])
+#undef WS_AVG1
+      return __builtin_bit_cast(u32x4, o);
+    };
+    auto raw8_avg = [&](u32x4 ra, u32x4 rb) -> u32x4 {
+      const V8 h = __builtin_bit_cast(V8, ra), k = __builtin_bit_cast(V8, rb);
+      V8 o;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = (T)(((float)h[i] + (float)k[i]) * 0.5f);
+      return __builtin_bit_cast(u32x4, o);
+    };
     auto stage = [&](const Raw& r, int slot) {
       char* const sb = smem + slot * ACT_STRIDE;
       const int um = __builtin_amdgcn_readfirstlane((int)r.meta);
@@ -342,8 +380,16 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
         } else {
           s0 = sp[0]; s1 = sp[1]; s2 = sp[2]; s3 = sp[3];
         }
-        o0 = xform8(r.a0, s0, s1, s2, s3);
-        o1 = xform8(r.a1, s0, s1, s2, s3);
+        if (AVG && (um & 16)) {
+          o0 = xform8_avg(r.a0, r.b0, s0, s1, s2, s3);
+          o1 = xform8_avg(r.a1, r.b1, s0, s1, s2, s3);
+        } else {
+          o0 = xform8(r.a0, s0, s1, s2, s3);
+          o1 = xform8(r.a1, s0, s1, s2, s3);
+        }
+      } else if (AVG && (um & 16)) {
+        o0 = raw8_avg(r.a0, r.b0);
+        o1 = raw8_avg(r.a1, r.b1);
       }
       const u32x4 z = {0u, 0u, 0u, 0u};
       if (!(VQVS_WS_EXP & 128)) {
@@ -399,7 +445,6 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
 #undef WS_PBODY
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the over-issued loads of the tail
     sync_lds();  // the consumers' last step
-    if constexpr (POST) sync_lds();  // (and their barrier before the last tile's statistics are combined)
 #ifdef VQVS_TIMING
     if (lane == 0 && ((int)blockIdx.x & 15) == 3) {
       for (int i = 0; i < 4; ++i) atomicAdd(&g_ws_timing[i], tacc[i]);
@@ -494,105 +539,6 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
           if (row + 1 < nvalid) *reinterpret_cast<u32x4*>(g + a.Cout) = o;
         }
       }
-    };
-
-    // ---- POST form of the epilogue ----
-    TileCo st_{0, 0, 0};      // tile whose partial statistics wait in R[spar ^ 1] for their combine (one barrier later)
-    bool stats_pending = false;
-    int spar = 0;
-    auto combine_stats = [&]() {
-      int zl = 0;
-      asm volatile("" : "+v"(zl));
-      const int ltid = tid + zl;
-      if (a.stats != nullptr && ltid < CT) {
-        const float2* const red = reinterpret_cast<const float2*>(smem + R_OFF) + (spar ^ 1) * 4 * CT;
-        float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {  // fixed order: deterministic
-          const float2 v = red[g * CT + ltid];
-          t1 += v.x;
-          t2 += v.y;
-        }
-        float2* o = reinterpret_cast<float2*>(a.stats) + ((size_t)st_.b * a.ntiles_stat + st_.tx) * a.Cout + st_.ty * CT + ltid;
-        *o = float2{t1, t2};
-      }
-      stats_pending = false;
-    };
-    auto epilogue_post = [&](const TileCo& tc) {
-      int zl = 0;
-      asm volatile("" : "+v"(zl));
-      const int t0 = tc.tx * a.TTO;
-      const int nvalid = min(a.TTO, a.Lout - t0);
-      const int lim = nvalid - (wt * 64 + 4 * hh) + zl;
-      if (wt * 64 + 64 > nvalid) {
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < WN; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              if (mt * 32 + (r & 3) + 8 * (r >> 2) >= lim) acc[mt][nt][r] = 0.f;
-      }
-      char* const reg = smem + O_OFF + wave * OW;
-      char* const ob = reg + (2 * hh) * RP + (l31 + zl) * 4;
-#pragma unroll
-      for (int nt = 0; nt < WN; ++nt) {
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int r = 0; r < 16; r += 2) {
-            char* const o0 = ob + (mt * 16 + ((r & 3) >> 1) + 4 * (r >> 2)) * RP + nt * 128;
-            if constexpr (WsOp<T>::one == 0x3C00) {
-              typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-              const h2 ones = {(_Float16)1.0f, (_Float16)1.0f};
-              const h2 pk = {(_Float16)acc[mt][nt][r], (_Float16)acc[mt][nt][r + 1]};
-              s1 = __builtin_amdgcn_fdot2(pk, ones, s1, false);
-              s2 = __builtin_amdgcn_fdot2(pk, pk, s2, false);
-              *reinterpret_cast<h2*>(o0) = pk;
-            } else {
-              typedef __bf16 b2 __attribute__((ext_vector_type(2)));
-              const b2 pk = {(__bf16)acc[mt][nt][r], (__bf16)acc[mt][nt][r + 1]};
-              const float v0 = (float)pk[0], v1 = (float)pk[1];
-              s1 += v0 + v1;
-              s2 = fmaf(v0, v0, fmaf(v1, v1, s2));
-              *reinterpret_cast<b2*>(o0) = pk;
-            }
-          }
-        s1 += __shfl_xor(s1, 32);
-        s2 += __shfl_xor(s2, 32);
-        if (hh == 0) reinterpret_cast<float2*>(smem + R_OFF)[spar * 4 * CT + wt * CT + wc * (WN * 32) + nt * 32 + l31 + zl] = float2{s1, s2};
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's own region: no barrier needed
-      // own region -> global: a lane takes 8 channels of a row pair, separates the rows, stores 16 B of each
-      constexpr int OPW = 4 * WN;         // 8-channel pieces per row
-      constexpr int PSTEP = 64 / OPW;     // row pairs per pass
-      const int lz = lane + zl;
-      const int p0 = lz / OPW, oc = lz - p0 * OPW;
-      T* const gdst = outp + ((size_t)tc.b * a.Lout + t0 + wt * 64 + 2 * p0) * a.Cout + tc.ty * CT + wc * (WN * 32) + oc * 8;
-#pragma unroll
-      for (int i = 0; i < 32 / PSTEP; ++i) {
-        const int row = wt * 64 + 2 * (p0 + i * PSTEP);
-        if (row < nvalid) {
-          const u32x4 lo = *reinterpret_cast<const u32x4*>(reg + (p0 + i * PSTEP) * RP + oc * 32);
-          const u32x4 hi = *reinterpret_cast<const u32x4*>(reg + (p0 + i * PSTEP) * RP + oc * 32 + 16);
-          u32x4 e, o;
-          e[0] = __builtin_amdgcn_perm(lo[1], lo[0], 0x05040100u);
-          e[1] = __builtin_amdgcn_perm(lo[3], lo[2], 0x05040100u);
-          e[2] = __builtin_amdgcn_perm(hi[1], hi[0], 0x05040100u);
-          e[3] = __builtin_amdgcn_perm(hi[3], hi[2], 0x05040100u);
-          o[0] = __builtin_amdgcn_perm(lo[1], lo[0], 0x07060302u);
-          o[1] = __builtin_amdgcn_perm(lo[3], lo[2], 0x07060302u);
-          o[2] = __builtin_amdgcn_perm(hi[1], hi[0], 0x07060302u);
-          o[3] = __builtin_amdgcn_perm(hi[3], hi[2], 0x07060302u);
-          T* const g = gdst + (size_t)(2 * i * PSTEP) * a.Cout;
-          *reinterpret_cast<u32x4*>(g) = e;
-          if (row + 1 < nvalid) *reinterpret_cast<u32x4*>(g + a.Cout) = o;
-        }
-      }
-      st_ = tc;
-      spar ^= 1;
-      stats_pending = true;
     };
 
     // chunk cursors: `ct` / `cci` = tile and chunk of the current step; the DMA cursor (tile `nt_`, segment `dseg`, chunk `dch`) runs
@@ -708,7 +654,7 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
       }
       WS_TMARK(2)
       // last chunk of the tile: statistics + rounding + out-tile
-      if (!POST && cci == n - 1 && (VQVS_WS_EXP & 32)) {
+      if (cci == n - 1 && (VQVS_WS_EXP & 32)) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -716,7 +662,7 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
         pt_ = ct;
         pending = true;
       }
-      if (!POST && cci == n - 1 && !(VQVS_WS_EXP & 32)) {
+      if (cci == n - 1 && !(VQVS_WS_EXP & 32)) {
         int zl = 0;
         asm volatile("" : "+v"(zl));
         const int t0 = ct.tx * a.TTO;
@@ -766,8 +712,6 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
         pending = true;
       }
       WS_TMARK(3)
-      const bool tile_done = cci == n - 1;
-      const TileCo done_tile = ct;
       if (++cci == n) {
         cci = 0;
         next_tile(ct);
@@ -788,17 +732,9 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
       } else {
         sync_all();
       }
-      if constexpr (POST) {
-        if (stats_pending) combine_stats();       // (the previous tile's partials: their barrier has passed)
-        if (tile_done) epilogue_post(done_tile);  // overlaps the producers' next chunk
-      }
       WS_TMARK(4)
     }
     if (pending) store_tile();
-    if constexpr (POST) {
-      sync_all();  // (the last tile's partial statistics; the producers match this barrier)
-      if (stats_pending) combine_stats();
-    }
 #ifdef VQVS_TIMING
     WS_TMARK(0)
     if (lane == 0 && ((int)blockIdx.x & 15) == 3) {
@@ -831,32 +767,32 @@ int ws_num_cus() {
 }
 
 template <int WN>
-constexpr int ws_fixed_lds(bool res, bool post = false) {  // LDS bytes besides resident weights
+constexpr int ws_fixed_lds(bool res) {  // LDS bytes besides resident weights
   constexpr int CT = 64 * WN;
-  return (res ? 2 * 256 * 64 + 2 * CT * 64 : 2 * (256 * 64 + 3 * CT * 64)) + (post ? 8 * 32 * (WN * 128 + 16) + 2 * 4 * CT * 8 : 128 * (CT * 4 + 16) + 4 * CT * 8);
+  return (res ? 2 * 256 * 64 + 2 * CT * 64 : 2 * (256 * 64 + 3 * CT * 64)) + 128 * (CT * 4 + 16) + 4 * CT * 8;
 }
 constexpr int WS_LDS_MAX = 160 * 1024;
 
-template <typename T, int WN, bool RES, bool POST>
+template <typename T, int WN, bool RES, bool AVG>
 int ws_launch(const WsArgs& w, hipStream_t st) {
-  const int lds = ws_fixed_lds<WN>(RES, POST) + (RES ? w.wres_bytes : 0) + w.ss_ring * w.ss_bytes;
+  const int lds = ws_fixed_lds<WN>(RES) + (RES ? w.wres_bytes : 0) + w.ss_ring * w.ss_bytes;
   static bool attr_done = false;
   if (!attr_done) {
-    VQVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<T, WN, RES, POST>), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_MAX));
+    VQVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<T, WN, RES, AVG>), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_MAX));
     attr_done = true;
   }
   const int grid = w.ntiles < ws_num_cus() ? w.ntiles : ws_num_cus();
-  hipLaunchKernelGGL((conv_ws_kernel<T, WN, RES, POST>), dim3(grid), dim3(1024), lds, st, w);
+  hipLaunchKernelGGL((conv_ws_kernel<T, WN, RES, AVG>), dim3(grid), dim3(1024), lds, st, w);
   VQVS_HIP(hipGetLastError());
   return 0;
 }
 template <typename T>
-int ws_launch_t(const WsArgs& w, int CT, bool res, bool post, hipStream_t st) {
+int ws_launch_t(const WsArgs& w, int CT, bool res, bool avg, hipStream_t st) {
   if (CT == 128) {
-    if (post) return res ? ws_launch<T, 2, true, true>(w, st) : ws_launch<T, 2, false, true>(w, st);
+    if (avg) return res ? ws_launch<T, 2, true, true>(w, st) : ws_launch<T, 2, false, true>(w, st);
     return res ? ws_launch<T, 2, true, false>(w, st) : ws_launch<T, 2, false, false>(w, st);
   }
-  if (post) return res ? ws_launch<T, 1, true, true>(w, st) : ws_launch<T, 1, false, true>(w, st);
+  if (avg) return res ? ws_launch<T, 1, true, true>(w, st) : ws_launch<T, 1, false, true>(w, st);
   return res ? ws_launch<T, 1, true, false>(w, st) : ws_launch<T, 1, false, false>(w, st);
 }
 
@@ -879,14 +815,18 @@ int ws_timing_read(unsigned long long* out32, int reset) {
 int launch_conv_ws(const ConvArgs& a, int B, int precision, hipStream_t st) {
   if (!ws_enabled() || precision == 0) return 0;
   if (a.Cout % 64 != 0 || a.out_f32 || a.epi_gelu || a.nbw || (a.out_rows != 0 && a.out_rows != a.Lout)) return 0;
-  if (a.skip != nullptr && (a.skip_resize != RESIZE_NONE || a.skip_C != a.Cout || a.skip_L != a.Lout)) return 0;
+  // rows per clip a source must have for a given resize (kernels.hpp RESIZE_*)
+  auto len_ok = [&](int rsz, int Lsrc) { return rsz == RESIZE_UP2 ? Lsrc * 2 == a.Lout : (rsz == RESIZE_AVG2 ? Lsrc / 2 == a.Lout : Lsrc == a.Lout); };
+  if (a.skip != nullptr && (a.skip_C != a.Cout || !len_ok(a.skip_resize, a.skip_L) || (long long)a.skip_L * a.skip_C * 2 >= (1LL << 29))) return 0;
+  bool avg = a.skip != nullptr && a.skip_resize == RESIZE_AVG2;
   const int CT = a.Cout % 128 == 0 ? 128 : 64;
   WsArgs w{};
   int dmax = 0, n = 0;
   for (int s = 0; s < a.nseg; ++s) {
     const SegDesc& g = a.seg[s];
-    if (g.resize != RESIZE_NONE || g.C % 32 != 0 || (g.ntaps != 1 && g.ntaps != 3) || g.Lsrc != a.Lout) return 0;
-    if ((long long)g.Lsrc * g.Csrc * 2 > 0x7fffffffLL) return 0;
+    if (g.C % 32 != 0 || (g.ntaps != 1 && g.ntaps != 3) || !len_ok(g.resize, g.Lsrc)) return 0;
+    if ((long long)g.Lsrc * g.Csrc * 2 >= (1LL << 29)) return 0;  // (the dummy loads of an AVG launch rely on offset + 2^30 being out of range)
+    avg = avg || g.resize == RESIZE_AVG2;
     WsSeg& q = w.seg[s];
     q.src = g.src;
     q.ss = g.ss;
@@ -896,6 +836,7 @@ int launch_conv_ws(const ConvArgs& a, int B, int precision, hipStream_t st) {
     q.nch = g.C / 32;
     q.ntaps = g.ntaps;
     q.dil = g.ntaps == 3 ? g.dil : 0;
+    q.rsz = g.resize;
     q.ss_stride = g.ss_stride;
     q.ss_c0 = g.ss_c0;
     q.ss_lds = w.ss_bytes;
@@ -918,6 +859,7 @@ int launch_conv_ws(const ConvArgs& a, int B, int precision, hipStream_t st) {
     q.nch = CT / 32;
     q.ntaps = 0;
     q.dil = 0;
+    q.rsz = a.skip_resize;
     n += q.nch;
   }
   if (a.tile_rows != 256 - 2 * dmax || a.w_bytes > 0x7fffffffLL || n < 2) return 0;
@@ -941,13 +883,8 @@ int launch_conv_ws(const ConvArgs& a, int B, int precision, hipStream_t st) {
   w.ss_ring = (long long)w.ntx * w.nty * n >= 4 ? 2 : 4;
   const int ss_total = w.ss_ring * w.ss_bytes;
   if ((CT == 128 ? ws_fixed_lds<2>(false) : ws_fixed_lds<1>(false)) + ss_total > WS_LDS_MAX) return 0;
-  // post-barrier, wave-private epilogue (measured SLOWER: op 64x3->64 at L = 64000 0.263 -> 0.292 ms; kept for A/B): 1 = the
-  // 64-channel tiles, 2 = every launch, 0 (default) = none
-  static const int post_env = getenv("VQVS_WS_POST") ? atoi(getenv("VQVS_WS_POST")) : 0;
-  const bool post = post_env == 2 || (post_env == 1 && CT == 64);
-  if ((CT == 128 ? ws_fixed_lds<2>(false, post) : ws_fixed_lds<1>(false, post)) + ss_total > WS_LDS_MAX) return 0;
-  const bool res = res_env && w.nty == 1 && (CT == 128 ? ws_fixed_lds<2>(true, post) : ws_fixed_lds<1>(true, post)) + w.wres_bytes + ss_total <= WS_LDS_MAX;
-  const int rc = precision == 2 ? ws_launch_t<half_t>(w, CT, res, post, st) : ws_launch_t<bf16_t>(w, CT, res, post, st);
+  const bool res = res_env && w.nty == 1 && (CT == 128 ? ws_fixed_lds<2>(true) : ws_fixed_lds<1>(true)) + w.wres_bytes + ss_total <= WS_LDS_MAX;
+  const int rc = precision == 2 ? ws_launch_t<half_t>(w, CT, res, avg, st) : ws_launch_t<bf16_t>(w, CT, res, avg, st);
   return rc < 0 ? rc : 1;
 }
 
