@@ -482,9 +482,15 @@ class Builder {
     const int cin = s.cin, cout = s.cout;
     const int in_shift = ins[0].lshift;
     const int out_shift = in_shift + (s.resize == RESIZE_AVG2 ? 1 : (s.resize == RESIZE_UP2 ? -1 : 0));
-    // With 64-channel output tiles every co-tile workgroup repeats the GroupNorm/GELU prologue of the same
-    // input rows; from 4 tiles up (Cout >= 256: only the short, deep levels) it is cheaper to run it once.
-    const bool pre_xform = cout >= 512;
+    // Prologue hoisted into its own kernel (the convolution then reads transformed rows raw):
+    //  - fp32 mode (conv_mfma_kernel: every channel-tile workgroup repeats the prologue of the same input rows): from 4 tiles up;
+    //  - 2-byte modes (conv_ws_kernel: the producers' prologue runs beside the MFMAs, measured cheaper than the extra pass from
+    //    512 channels too): only where the per-clip (scale, shift) table of the launch does not fit the CU's LDS next to the
+    //    tiles -- conv 1 over a concatenated 1024-channel input.
+    static const int pre_xform_min = getenv("VQVS_PRE_XFORM_MIN") ? atoi(getenv("VQVS_PRE_XFORM_MIN")) : 0;  // (A/B: > 0 = hoist from this Cout up, both convs)
+    const bool two_byte = m_->cfg.precision != VQVS_PREC_F32;
+    const bool pre_xform1 = pre_xform_min > 0 ? cout >= pre_xform_min : (two_byte ? cin >= 1024 : cout >= 512);
+    const bool pre_xform2 = pre_xform_min > 0 ? cout >= pre_xform_min : (two_byte ? false : cout >= 512);
     // GroupNorm 1 coefficients over the (virtually concatenated) input
     const size_t ss1 = alloc_ss(cin);
     const size_t mr1 = rec ? alloc_ss(cin) : 0;
@@ -499,7 +505,7 @@ class Builder {
       std::vector<TensorH> tmp;
       for (auto& t : ins) {
         SegSpec g{t, 0, t.C, 3, 1, s.resize, true, ss1, cin, cb, 0};
-        if (pre_xform) {  // prologue hoisted out of the GEMM: the conv reads g raw
+        if (pre_xform1) {  // prologue hoisted out of the GEMM: the conv reads g raw
           g.t = add_xform(t, ss1, cin, cb, s.resize == RESIZE_AVG2);
           g.xform = false;
           if (s.resize == RESIZE_AVG2) g.resize = RESIZE_NONE;
@@ -528,7 +534,7 @@ class Builder {
       std::vector<float> bias(b, b + cout);
       SegSpec g{h1, 0, cout, 3, s.dil, RESIZE_NONE, true, ss2, cout, 0, 0};
       TensorH g2{};
-      if (pre_xform) {
+      if (pre_xform2) {
         g2 = add_xform(h1, ss2, cout, 0, false);
         g.t = g2;
         g.xform = false;
@@ -550,7 +556,7 @@ class Builder {
       } else {  // identity skip (never together with a concatenated input in this topology)
         add_conv(segs, pk, bias, cout, out, &ins[0], s.resize);
       }
-      if (pre_xform) release(g2);
+      if (pre_xform2) release(g2);
     }
     release(h1);
     if (rec) *rec = BlockRec{s, ins[0], ins.size() > 1 ? ins[1] : TensorH{}, h1, out, ss1, ss2, mr1, mr2};
