@@ -391,10 +391,15 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
         o0 = raw8_avg(r.a0, r.b0);
         o1 = raw8_avg(r.a1, r.b1);
       }
-      const u32x4 z = {0u, 0u, 0u, 0u};
       if (!(VQVS_WS_EXP & 128)) {
-        if (!(r.meta & 2u)) o0 = z;
-        if (!(r.meta & 4u)) o1 = z;
+        // rows outside the clip are the convolution's zero padding: AND with a 0 / ~0 lane mask (v_bfe_i32 + v_and_b32; a
+        // v_cndmask_b32 on VCC measured ~7x the issue cost of a v_and_b32, tools/ubench/valu_mix.hip)
+        const unsigned m0 = (unsigned)__builtin_amdgcn_sbfe((int)r.meta, 1, 1), m1 = (unsigned)__builtin_amdgcn_sbfe((int)r.meta, 2, 1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o0[e] &= m0;
+          o1[e] &= m1;
+        }
       }
       *reinterpret_cast<u32x4*>(sb + dst0) = o0;
       *reinterpret_cast<u32x4*>(sb + dst0 + 128 * 64) = o1;
