@@ -166,28 +166,43 @@ __global__ __launch_bounds__(256) void gn_prepare_kernel(const GnArgs a) {
       const GnSrc g = second ? a.src[1] : a.src[0];
       const int cl = second ? c - C0 : c;
       const float* p = g.partials + (size_t)b * g.ntiles * g.C * 2;
-      for (int t = sl; t < g.ntiles; t += nsl) {
-        const float2 q = *reinterpret_cast<const float2*>(p + ((size_t)t * g.C + cl) * 2);
-        s1 += (double)q.x;
-        s2 += (double)q.y;
-        // range guard (the statistics are fp32 sums of the stored values): a non-finite partial means an activation overflowed the
-        // storage type; in the fp16 mode a tile whose sum of squares reaches 9e8 may hold an element beyond 3e4 (of 65504)
-        if (!(fabsf(q.x) <= 3.0e38f) || !(q.y <= 3.0e38f)) bad |= 1u;
-        if (a.guard && q.y >= 9.0e8f) bad |= 2u;
+      // eight independent loads in flight per thread (the partials of a long clip are 250 tiles deep: one load per iteration
+      // made this kernel a chain of memory latencies); the additions keep their order, so the result is unchanged
+      for (int t0 = sl; t0 < g.ntiles; t0 += 8 * nsl) {
+        float2 q[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int t = t0 + k * nsl;
+          q[k] = t < g.ntiles ? *reinterpret_cast<const float2*>(p + ((size_t)t * g.C + cl) * 2) : float2{0.f, 0.f};
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          s1 += (double)q[k].x;
+          s2 += (double)q[k].y;
+          // range guard (the statistics are fp32 sums of the stored values): a non-finite partial means an activation overflowed
+          // the storage type; in the fp16 mode a tile whose sum of squares reaches 9e8 may hold an element beyond 3e4 (of 65504)
+          if (!(fabsf(q[k].x) <= 3.0e38f) || !(q[k].y <= 3.0e38f)) bad |= 1u;
+          if (a.guard && q[k].y >= 9.0e8f) bad |= 2u;
+        }
       }
       part[tid * 2] = s1;
       part[tid * 2 + 1] = s2;
     }
     if (bad && a.status) atomicOr(a.status, bad);
     __syncthreads();
-    if (tid < cw) {
-      double t1 = 0.0, t2 = 0.0;
-      for (int k = 0; k < nsl; ++k) {  // fixed order: deterministic
-        t1 += part[(k * cw + tid) * 2];
-        t2 += part[(k * cw + tid) * 2 + 1];
+    // slices of a channel: pairwise tree of fixed shape (deterministic), log2(nsl) steps instead of nsl serial LDS reads
+    int top = 1;
+    while (top < nsl) top <<= 1;
+    for (int st = top >> 1; st >= 1; st >>= 1) {
+      if (sl < st && sl + st < nsl) {
+        part[tid * 2] += part[(tid + st * cw) * 2];
+        part[tid * 2 + 1] += part[(tid + st * cw) * 2 + 1];
       }
-      chs[c0 + tid] = t1;
-      chq[c0 + tid] = t2;
+      __syncthreads();
+    }
+    if (tid < cw) {
+      chs[c0 + tid] = part[tid * 2];
+      chq[c0 + tid] = part[tid * 2 + 1];
     }
     __syncthreads();
   }
