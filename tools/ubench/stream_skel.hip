@@ -37,7 +37,7 @@ __device__ __forceinline__ u32x4 xform8(u32x4 raw, f32x4 s0, f32x4 s1, f32x4 s2,
   return __builtin_bit_cast(u32x4, o);
 }
 
-template <int MODE /*1 loads, 2 stores, 3 both*/, int DEPTH, int C, int COMP /*1 producer prologue, 2 consumer MFMAs, 4 weight DMA per step, 8 tile-end statistics + rounding into LDS, 16 wave-private epilogue + store BEHIND the barrier, 32 the PRODUCERS issue the weight DMA, 64 packed-fp32 statistics instead of v_dot2c*/>
+template <int MODE /*1 loads, 2 stores, 3 both*/, int DEPTH, int C, int GEOM /*0: 256-row aligned tiles; else the convolution's geometry inside 64000-row clips with clip-wide descriptors: tile tx starts at row tx * (GEOM >> 8) - (GEOM & 255)*/, int COMP /*1 producer prologue, 2 consumer MFMAs, 4 weight DMA per step, 8 tile-end statistics + rounding into LDS, 16 wave-private epilogue + store BEHIND the barrier, 32 the PRODUCERS issue the weight DMA, 64 packed-fp32 statistics instead of v_dot2c*/>
 __global__ __launch_bounds__(1024) void k(const char* __restrict__ src, char* __restrict__ dst, int tiles_total) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NCH = C / 32;
@@ -46,7 +46,9 @@ __global__ __launch_bounds__(1024) void k(const char* __restrict__ src, char* __
   const int k8 = blockIdx.x & 7, i8 = blockIdx.x >> 3, nk = gridDim.x / 8;
   const int xs = (int)((long long)tiles_total * k8 / 8), xe = (int)((long long)tiles_total * (k8 + 1) / 8);
   const int tb = xs + (xe - xs) * i8 / nk, te = xs + (xe - xs) * (i8 + 1) / nk;
-  const int Q = (te - tb) * NCH;
+  constexpr int GTk = GEOM ? (64000 + ((GEOM >> 8) & 0xffff) - 1) / ((GEOM >> 8) & 0xffff) : 1;
+  const int nclip_k = tiles_total / GTk;
+  const int Q = ((GEOM >> 26) & 1) ? ((GTk - ((int)blockIdx.x & 3) + 3) / 4) * ((nclip_k - ((int)blockIdx.x >> 2) + 63) / 64) * NCH : ((GEOM >> 27) & 1 ? (tiles_total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : (te - tb)) * NCH;  // (bit 27: workgroup w takes tiles w, w + grid, ...)
   if (Q <= 0) return;
   if (wave >= 8) {
     const int pt = tid - 512, oct = pt & 3, r0 = pt >> 2;
@@ -55,15 +57,29 @@ __global__ __launch_bounds__(1024) void k(const char* __restrict__ src, char* __
     int q_issue = 0;
     auto issue = [&](u32x4& x0, u32x4& x1) {
       const int qq = q_issue < Q ? q_issue : Q - 1;
-      const int t = tb + qq / NCH, c = qq % NCH;
-      const char* base = src + (long long)t * 256 * C * 2;
+      int t = ((GEOM >> 27) & 1) ? (int)blockIdx.x + (qq / NCH) * (int)gridDim.x : tb + qq / NCH;
+      const int c = qq % NCH;
+      if ((GEOM >> 26) & 1) {  // bit 26: groups of 4 workgroups sweep one clip at a time, tiles dealt round-robin inside the group
+        constexpr int GTc = GEOM ? (64000 + ((GEOM >> 8) & 0xffff) - 1) / ((GEOM >> 8) & 0xffff) : 1;
+        const int j = (int)blockIdx.x & 3, g = (int)blockIdx.x >> 2, per = (GTc - j + 3) / 4;  // tiles of this workgroup per clip
+        const int i = qq / NCH, r = i / per, ii = i - r * per;
+        t = (g + r * 64) * GTc + j + 4 * ii;
+      }
+      constexpr int GT = GEOM ? (64000 + ((GEOM >> 8) & 0xffff) - 1) / ((GEOM >> 8) & 0xffff) : 1;
+      const int clip = GEOM ? t / GT : 0, tx = t - clip * GT;
+      // GEOM bit 30: descriptor base = the tile's first row (small offsets), records = what is left of the clip;
+      // bit 29: the same with records = the 256 rows of the tile only
+      constexpr bool WIN = (GEOM >> 29) & 3;
+      const int wrow = WIN ? tx * ((GEOM >> 8) & 0xffff) - (GEOM & 255) : 0;
+      const int brow = wrow > 0 ? wrow : 0;
+      const char* base = GEOM ? src + (long long)clip * 64000 * C * 2 + (long long)brow * C * 2 : src + (long long)t * 256 * C * 2;
       i32x4 rs;
       const unsigned long long bp = reinterpret_cast<unsigned long long>(base);
       rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)bp);
       rs[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(bp >> 32) & 0xffffu));
-      rs[2] = 256 * C * 2;
+      rs[2] = GEOM ? (((GEOM >> 29) & 1) ? 256 * C * 2 : (64000 - brow) * C * 2) : 256 * C * 2;
       rs[3] = 0x00020000;
-      const int off0 = (r0 * C + c * 32 + oct * 8) * 2, off1 = off0 + 256 * C;
+      const int off0 = ((r0 + (GEOM ? tx * ((GEOM >> 8) & 0xffff) - (GEOM & 255) - brow : 0)) * C + c * 32 + oct * 8) * 2, off1 = off0 + 256 * C;
       if (MODE & 1)
         asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %4, 0 offen\n\tbuffer_load_dwordx4 %1, %3, %4, 0 offen" : "=&v"(x0), "=&v"(x1) : "v"(off0), "v"(off1), "s"(rs));
       else
@@ -107,7 +123,9 @@ __global__ __launch_bounds__(1024) void k(const char* __restrict__ src, char* __
     __builtin_amdgcn_s_barrier();
   } else {
     __builtin_amdgcn_s_barrier();
-    int tile = tb;
+    constexpr bool ILV = (GEOM >> 27) & 1;
+    int tile = ILV ? (int)blockIdx.x : tb;
+    const int tstep = ILV ? (int)gridDim.x : 1;
     const int lane = tid & 63, wt = wave & 3, wc = wave >> 2, l31 = lane & 31, hh = lane >> 5;
     f32x16 acc[2][2];
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
@@ -150,8 +168,8 @@ __global__ __launch_bounds__(1024) void k(const char* __restrict__ src, char* __
           const u32x4 v = *reinterpret_cast<const u32x4*>(smem + 32768 + ((i * 512 + tid) * 16) % 32768);
           *reinterpret_cast<u32x4*>(o + (long long)(i * 512 + tid) * 16) = v;
         }
-        ++tile;
-      } else if (c == NCH - 1) ++tile;
+        tile += tstep;
+      } else if (c == NCH - 1) tile += tstep;
       if ((COMP & 8) && c == NCH - 1) {
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
         const h2 ones = {(_Float16)1.0f, (_Float16)1.0f};
@@ -214,7 +232,7 @@ __global__ __launch_bounds__(1024) void k(const char* __restrict__ src, char* __
         for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.5f;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (MODE & 2) {
-          char* o = dst + (long long)(tile - 1) * 256 * C * 2 + (long long)(wt * 64) * C * 2 + wc * 128;
+          char* o = dst + (long long)(tile - tstep) * 256 * C * 2 + (long long)(wt * 64) * C * 2 + wc * 128;
           // lane -> (row pair p = lane >> 3 (+8 per iteration), 8-channel piece q = lane & 7): 2 x 16 B of LDS -> two rows x 16 B
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -240,30 +258,38 @@ __global__ __launch_bounds__(1024) void k(const char* __restrict__ src, char* __
   }
 }
 
-template <int MODE, int DEPTH, int C, int COMP = 0>
+static int g_tiles_override = 0;
+template <int MODE, int DEPTH, int C, int COMP = 0, int GEOM = 0>
 void run(const char* s, char* d, long long bytes) {
-  const int tiles = (int)(bytes / (256 * C * 2));
+  const int tiles = GEOM ? (int)(bytes / (64000 * C * 2)) * ((64000 + ((GEOM >> 8) & 0xffff) - 1) / ((GEOM >> 8) & 0xffff)) : (int)(bytes / (256 * C * 2));
+  const int tiles0 = tiles;
+  (void)tiles0;
   const int LDS = 112 * 1024;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k<MODE, DEPTH, C, COMP>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k<MODE, DEPTH, C, GEOM, COMP>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
-  hipLaunchKernelGGL((k<MODE, DEPTH, C, COMP>), dim3(256), dim3(1024), LDS, 0, s, d, tiles);
+  hipLaunchKernelGGL((k<MODE, DEPTH, C, GEOM, COMP>), dim3(256), dim3(1024), LDS, 0, s, d, g_tiles_override ? g_tiles_override : tiles);
   (void)hipEventRecord(e0);
-  for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((k<MODE, DEPTH, C, COMP>), dim3(256), dim3(1024), LDS, 0, s, d, tiles);
+  for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((k<MODE, DEPTH, C, GEOM, COMP>), dim3(256), dim3(1024), LDS, 0, s, d, g_tiles_override ? g_tiles_override : tiles);
   (void)hipEventRecord(e1);
   (void)hipEventSynchronize(e1);
   float ms;
   (void)hipEventElapsedTime(&ms, e0, e1);
   const double moved = (double)bytes * ((MODE & 1 ? 1 : 0) + (MODE & 2 ? 1 : 0)) * 5;
-  printf("  C=%3d depth %d %-12s compute %d: %7.3f ms per pass, %5.2f TB/s\n", C, DEPTH, MODE == 0 ? "no memory" : MODE == 1 ? "loads only" : MODE == 2 ? "stores only" : "loads+stores", COMP, ms / 5, moved / (ms * 1e-3) / 1e12);
+  if (g_tiles_override) {
+    printf("%7.4f ms per pass, %5.2f TB/s\n", ms / 5, (double)g_tiles_override * 256 * C * 2 * ((MODE & 1 ? 1 : 0) + (MODE & 2 ? 1 : 0)) * 5 / (ms * 1e-3) / 1e12);
+    return;
+  }
+  printf("  C=%3d depth %d geom %d %-12s compute %d: %7.3f ms per pass, %5.2f TB/s\n", C, DEPTH, GEOM, MODE == 0 ? "no memory" : MODE == 1 ? "loads only" : MODE == 2 ? "stores only" : "loads+stores", COMP, ms / 5, moved / (ms * 1e-3) / 1e12);
 }
 
 int main() {
   const long long bytes = 512ll << 20;
   char *s, *d;
   (void)hipMalloc(&s, bytes);
-  (void)hipMalloc(&d, bytes);
+  (void)hipMalloc(&d, bytes + (128ll << 20));  // (the geometry variants have up to 15 % more tiles)
+  setvbuf(stdout, nullptr, _IOLBF, 0);
   {  // random fp16 activations in [-2, 2): constant data would let the chip clock higher than real data does
     unsigned short* h = (unsigned short*)malloc(bytes);
     unsigned x = 12345u;
@@ -274,6 +300,31 @@ int main() {
     }
     (void)hipMemcpy(s, h, bytes, hipMemcpyHostToDevice);
     free(h);
+  }
+  if (getenv("SKEL_GEOM")) {
+    // (TB/s figures of the geometry rows count the tensor once; overlapping tiles re-read their halo through L2)
+    run<1, 3, 64, 0, 0>(s, d, bytes);
+    for (int n : {16384, 16250, 16128, 16000}) {
+      printf("%5d tiles (%.3f per workgroup), contiguous ranges : ", n, n / 256.0);
+      g_tiles_override = n;
+      run<1, 3, 64, 0, 0>(s, d, bytes);
+      printf("%5d tiles (%.3f per workgroup), interleaved       : ", n, n / 256.0);
+      run<1, 3, 64, 0, (1 << 27) + 256 * 256>(s, d, bytes);
+    }
+    g_tiles_override = 0;
+    printf("the convolution's geometry (252-row tiles + 2 halo rows each side, 65 clips), contiguous / interleaved:\n");
+    run<1, 3, 64, 0, 252 * 256 + 2>(s, d, bytes);
+    run<1, 3, 64, 0, (1 << 27) + 252 * 256 + 2>(s, d, bytes);
+    printf("groups of 4 workgroups per clip:\n");
+    run<1, 3, 64, 0, (1 << 26) + 252 * 256 + 2>(s, d, bytes);
+    run<1, 3, 64, 0, (1 << 26) + 254 * 256 + 1>(s, d, bytes);
+    run<1, 3, 128, 0, (1 << 26) + 252 * 256 + 2>(s, d, bytes);
+    run<1, 3, 64, 0, 254 * 256 + 1>(s, d, bytes);
+    run<1, 3, 64, 0, (1 << 27) + 254 * 256 + 1>(s, d, bytes);
+    run<3, 3, 64, 0, 254 * 256 + 1>(s, d, bytes);
+    run<3, 3, 64, 0, (1 << 27) + 254 * 256 + 1>(s, d, bytes);
+    g_tiles_override = 0;
+    return 0;
   }
   run<1, 3, 64>(s, d, bytes);
   run<2, 3, 64>(s, d, bytes);

@@ -41,11 +41,13 @@ def run(cin, cout, Lx, B, prec="fp16", dil=2, emb=256):
     if pw == 0:
         print(f"--- ResBlock {cin}->{cout} L={Lx}: not on the wave-specialised kernel")
         return
-    print(f"--- ResBlock {cin}->{cout} L={Lx} B={B} {prec} d={dil} (both convs): {steps / pw:.0f} steps, {tiles / cw:.1f} tiles per sampled wave")
+    print(f"--- ResBlock {cin}->{cout} L={Lx} B={B} {prec} d={dil} (both convs): {steps / pw:.0f} steps, {tiles / max(cw, 1):.1f} tiles per sampled wave")
     ptot, ctot = sum(t[0:4]), sum(t[8:13])
     print(f"   producers: {ptot / steps:8.0f} ticks per step")
     for name, v in zip(P_PH, t[0:4]):
         print(f"      {name:28s} {v / steps:8.0f}  {100 * v / ptot:5.1f}%")
+    if cw == 0:  # (an ablation build whose consumers only keep the barriers)
+        return
     csteps = steps * cw / pw
     print(f"   consumers: {ctot / csteps:8.0f} ticks per step")
     for name, v in zip(C_PH, t[8:13]):

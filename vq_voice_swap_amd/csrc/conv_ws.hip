@@ -108,7 +108,8 @@ struct TileCo {
 
 #ifndef VQVS_WS_EXP
 #define VQVS_WS_EXP 0  // ablation bits for tools/experiments (results are WRONG when non-zero): 1 no activation loads, 2 no weight DMA,
-#endif                // 4 no tile store, 8 no prologue arithmetic, 16 no MFMA loop, 32 no tile-end statistics / rounding
+#endif                // 4 no tile store, 8 no prologue arithmetic, 16 no MFMA loop, 32 no tile-end statistics / rounding, 64 constant
+                      // (scale, shift), 128 no zero masks, 256 store at the step's start, 1024 idle consumers, 2048 trivial load cursor
 
 #ifdef VQVS_TIMING
 __device__ unsigned long long g_ws_timing[32];
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
       // raw buffer descriptor of this clip's rows: out-of-range rows (before / after the clip) read as zero
       cur.rs[0] = (int)(unsigned)clip;
       cur.rs[1] = (int)((unsigned)(clip >> 32) & 0xffffu);
-      cur.rs[2] = f.clip_bytes;
+      cur.rs[2] = (VQVS_WS_EXP & 2048) ? 0x7fffffff : f.clip_bytes;
       cur.rs[3] = 0x00020000;
       const int tm0 = lt.tx * a.TTO - f.dil + r0, tm1 = tm0 + 128;  // time of this thread's two rows
       const int sr0 = f.rsz == RESIZE_UP2 ? (tm0 >> 1) : (f.rsz == RESIZE_AVG2 ? 2 * tm0 : tm0);  // (first) source row of row 0
@@ -278,6 +279,14 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
     auto prepare = [&]() -> Prep {
       Prep pr = cur;
       pr.meta = cur_valid | (unsigned)(cur_xf | (cur_id << 3) | (cur_avg << 4) | (cur_idch << 8));
+      if (VQVS_WS_EXP & 2048) {  // ablation (valid for a single 64-channel segment only): the cheapest possible cursor
+        ++issued;
+        const int adv = (issued & 1) ? 64 : a.TTO * 128 - 64;
+        cur.off0 += adv;
+        cur.off1 += adv;
+        cur.ssaddr ^= 256;
+        return pr;
+      }
       if (++issued < Q) {  // (past the end the last chunk is simply loaded again and never staged)
         if (++lch == lnch) {
           lch = 0;
@@ -596,6 +605,10 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // first chunk's (or all resident) weights have landed
     sync_all();
     WS_TMARK(4)
+    if (VQVS_WS_EXP & 1024) {  // ablation: the consumers only keep the barrier count
+      for (int g = 0; g < Q; ++g) sync_all();
+      return;
+    }
     for (int g = 0; g < Q; ++g) {
       if (cci == 0) {  // first chunk of a tile
         if ((VQVS_WS_EXP & 256) && pending) {
@@ -786,7 +799,9 @@ int ws_launch(const WsArgs& w, hipStream_t st) {
     VQVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<T, WN, RES, AVG>), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_MAX));
     attr_done = true;
   }
-  const int grid = w.ntiles < ws_num_cus() ? w.ntiles : ws_num_cus();
+  static const int grid_env = getenv("VQVS_WS_GRID") ? atoi(getenv("VQVS_WS_GRID")) : 0;  // (A/B measurements: workgroups per launch)
+  const int ncu = grid_env > 0 ? grid_env : ws_num_cus();
+  const int grid = w.ntiles < ncu ? w.ntiles : ncu;
   hipLaunchKernelGGL((conv_ws_kernel<T, WN, RES, AVG>), dim3(grid), dim3(1024), lds, st, w);
   VQVS_HIP(hipGetLastError());
   return 0;
