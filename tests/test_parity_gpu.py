@@ -368,6 +368,35 @@ def test_resblock_config_sweep_vs_oracle(dev, prec, tol):
         assert got.shape == want.shape and rel_rms(got, want) < tol, (i, cin, cout, scale, dil, L, B, rel_rms(got, want))
 
 
+def test_resblock_random_configs_vs_oracle(dev):
+    """Seeded random ResBlocks (channel counts, lengths around the tile boundaries, dilations, avg / up resizing, FiLM on / off,
+    several clips per workgroup) in the two gate modes: the sweep of tools/fuzz_resblock.py with a fixed seed.  Covers the
+    wave-specialised convolution kernel's segment / tile / clip bookkeeping well beyond the shapes of the UNets."""
+    import random
+    rng = random.Random(11)
+    worst = {"fp32": 0.0, "fp16": 0.0}
+    for i in range(28):
+        cin = rng.choice([32, 64, 96, 128, 192, 256, 384, 512])
+        scale = rng.choice([1.0, 1.0, 0.5, 2.0])
+        cout = cin if scale != 1.0 else rng.choice([cin, 64, 128, 256, 512])
+        dil = 2 if scale == 2.0 else rng.choice([1, 2, 2, 4, 8, 16, 32])
+        emb = rng.choice([None, 128, 256])
+        L = rng.choice([2, 6, 64, 126, 250, 252, 254, 256, 258, 500, 508, 510, 1000, 1024, rng.randrange(2, 1500) * 2])
+        B = rng.choice([1, 2, 3, 5])
+        m = ResBlockModule(cin, emb, cout if cout != cin else None, scale, dil)
+        det_init_((f"rnd{i}." + k, v) for k, v in m.block.state_dict().items())
+        x = seeded((B, cin, L), 7000 + i)
+        e = seeded((B, emb), 8000 + i) if emb else None
+        sd = {"b." + k: v.detach() for k, v in m.block.state_dict().items()}
+        want = ref_cpu.res_block(x, sd, "b", dict(cin=cin, cout=cout, scale=scale, dil=dil), e)
+        for prec, tol in (("fp32", FP32_REL), ("fp16", FP16_REL)):
+            m.set_precision(prec)
+            got = m(x.to(dev), None if e is None else e.to(dev)).cpu()
+            err = rel_rms(got, want) if got.shape == want.shape else float("inf")
+            worst[prec] = max(worst[prec], err)
+            assert err < tol, (prec, dict(cin=cin, cout=cout, scale=scale, dil=dil, emb=emb, L=L, B=B), err)
+
+
 def test_handle_lifecycle_and_small_shapes(dev):
     """The device handle is rebuilt when batch / length grow or precision changes; tiny shapes work; memory is returned."""
     model = det_model(DiffusionModel("unet", 32))
