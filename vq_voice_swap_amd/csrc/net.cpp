@@ -486,10 +486,10 @@ class Builder {
     //  - fp32 mode (conv_mfma_kernel: every channel-tile workgroup repeats the prologue of the same input rows): from 4 tiles up;
     //  - 2-byte modes (conv_ws_kernel: the producers' prologue runs beside the MFMAs, measured cheaper than the extra pass from
     //    512 channels too): only where the per-clip (scale, shift) table of the launch does not fit the CU's LDS next to the
-    //    tiles -- conv 1 over a concatenated 1024-channel input.
+    //    tiles -- conv 1 over a concatenated input of more than 640 channels (768 and 1024 in the UNets).
     static const int pre_xform_min = getenv("VQVS_PRE_XFORM_MIN") ? atoi(getenv("VQVS_PRE_XFORM_MIN")) : 0;  // (A/B: > 0 = hoist from this Cout up, both convs)
     const bool two_byte = m_->cfg.precision != VQVS_PREC_F32;
-    const bool pre_xform1 = pre_xform_min > 0 ? cout >= pre_xform_min : (two_byte ? cin >= 1024 : cout >= 512);
+    const bool pre_xform1 = pre_xform_min > 0 ? cout >= pre_xform_min : (two_byte ? cin > 640 : cout >= 512);  // (2 x 8 B x cin of table beside the tiles)
     const bool pre_xform2 = pre_xform_min > 0 ? cout >= pre_xform_min : (two_byte ? false : cout >= 512);
     // GroupNorm 1 coefficients over the (virtually concatenated) input
     const size_t ss1 = alloc_ss(cin);
