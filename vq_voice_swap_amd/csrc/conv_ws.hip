@@ -903,7 +903,9 @@ int launch_conv_ws(const ConvArgs& a, int B, int precision, hipStream_t st) {
   w.ss_ring = (long long)w.ntx * w.nty * n >= 4 ? 2 : 4;
   const int ss_total = w.ss_ring * w.ss_bytes;
   if ((CT == 128 ? ws_fixed_lds<2>(false) : ws_fixed_lds<1>(false)) + ss_total > WS_LDS_MAX) return 0;
-  const bool res = res_env && w.nty == 1 && (CT == 128 ? ws_fixed_lds<2>(true) : ws_fixed_lds<1>(true)) + w.wres_bytes + ss_total <= WS_LDS_MAX;
+  // (avg-pooled launches stream their weights: resident weights + four loads per chunk do not fit 128 VGPRs without spills, and
+  //  compiler-generated scratch traffic has no place beside the producers' counted waits)
+  const bool res = res_env && !avg && w.nty == 1 && (CT == 128 ? ws_fixed_lds<2>(true) : ws_fixed_lds<1>(true)) + w.wres_bytes + ss_total <= WS_LDS_MAX;
   const int rc = precision == 2 ? ws_launch_t<half_t>(w, CT, res, avg, st) : ws_launch_t<bf16_t>(w, CT, res, avg, st);
   return rc < 0 ? rc : 1;
 }
