@@ -1,5 +1,6 @@
 """Randomised ResBlock parity sweep (HIP vs oracle): random channel counts, lengths (incl. tile-boundary cases),
-dilations, resizes, FiLM on/off, batch sizes, all three precision modes.  Developer tool; tests/ hold the fixed cases."""
+dilations, resizes, FiLM on/off, batch sizes, all three precision modes.  Developer tool; tests/ hold the fixed cases.
+    python tools/fuzz_resblock.py [seed] [cases] [big]      ("big": every fourth case is a long, many-clip launch)"""
 import os, random, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -12,6 +13,7 @@ from util import rel_rms, seeded
 dev = torch.device("cuda:0")
 rng = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+BIG = len(sys.argv) > 3 and sys.argv[3] == "big"
 worst = {"fp32": 0.0, "fp16": 0.0, "bf16": 0.0}
 bad = 0
 for i in range(N):
@@ -22,6 +24,11 @@ for i in range(N):
     emb = rng.choice([None, 128, 256])
     L = rng.choice([2, 6, 64, 126, 250, 252, 254, 256, 258, 500, 508, 510, 1000, 1024, rng.randrange(2, 1500) * 2])
     B = rng.choice([1, 2, 3, 5])
+    if BIG and i % 4 == 0:  # many tiles per workgroup and workgroups that cross clip boundaries (the (scale, shift) ring)
+        L = rng.choice([4000, 6002, 8190, 12000])
+        B = rng.choice([24, 37, 48])
+        cin = rng.choice([64, 128])
+        cout = cin if scale != 1.0 else rng.choice([cin, 64, 128])
     m = ResBlockModule(cin, emb, cout if cout != cin else None, scale, dil)
     det_init_((f"fz{i}." + k, v) for k, v in m.block.state_dict().items())
     x = seeded((B, cin, L), 5000 + i)
