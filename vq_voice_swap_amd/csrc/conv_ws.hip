@@ -8,7 +8,7 @@
 //                (GroupNorm/FiLM affine + GELU, reference unet.py:280-285, 311-315) as scalar fp32 VALU, ds_write of MFMA operands.
 //   waves 0..7   CONSUMERS: weight chunks by LDS-DMA (buffer_load ... lds, no registers), ds_read fragments, MFMAs; at the
 //                end of a tile the statistics of the next GroupNorm and ONE rounding to the storage type into an LDS out-tile,
-//                which they store as whole rows at the beginning of the next step.
+//                which they store as whole rows one step later (behind that step's weight wait).
 //   One s_barrier per K chunk ("step"): during step g the consumers multiply chunk g (stage g & 1) while the producers stage
 //   chunk g + 1 (stage (g + 1) & 1) -- across tile boundaries too, so there is no per-tile pipeline fill.
 //   The identity skip (unet.py:316) is one more K segment whose B operand is the identity matrix: x * 1.0 accumulates exactly in
