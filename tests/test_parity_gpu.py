@@ -435,7 +435,21 @@ def test_live_parameters_deepcopy_and_index_errors(dev):
     assert torch.equal(b, 2.0 * a)
     ema = copy.deepcopy(model)
     assert torch.equal(ema.predictor(x, ts), b)
+    # a REPLACED parameter object is seen too (the module tree is walked on every call) ...
+    conv = model.predictor.out[1]
+    conv.weight = torch.nn.Parameter(conv.weight.detach() * 0.5)
+    conv.bias = torch.nn.Parameter(conv.bias.detach() * 0.5)
+    assert torch.equal(model.predictor(x, ts), a)
+    # ... a write through .data is not (no version bump): the documented contract is invalidate()
+    conv.weight.data.mul_(2.0)
+    conv.bias.data.mul_(2.0)
+    model.predictor.invalidate()
+    assert torch.equal(model.predictor(x, ts), b)
+    with torch.no_grad():
+        conv.weight.mul_(0.5)
+        conv.bias.mul_(0.5)
     pickle.dumps(model.predictor)  # the ctypes handle is dropped from the pickled state
+    assert torch.equal(model.predictor(x, ts), a)
     src = det_model(DiffusionModel("unet", 32))
     assert model.load_from_pretrained(src) > 0
     assert torch.equal(model.predictor(x, ts), a)
