@@ -44,10 +44,49 @@ __device__ __forceinline__ f32x16 ws_mfma(f16x8 a, f16x8 b, f32x16 c) { return _
 
 // The prologue arithmetic is written on scalars on purpose: a packed fp32 instruction (v_pk_fma_f32) does not run beside
 // another wave's MFMAs on the same SIMD, a plain one does (profiles/r02_ubench_role_split.txt).
+// Eight elements at a time, Horner step by Horner step: left to itself the scheduler emits each element's dependent chain
+// back to back (seven v_fmaak in a row, every one waiting for its predecessor's result); the scheduling barriers keep eight
+// independent instructions between an instruction and its consumer, which is what a wave needs to issue VALU at full rate.
+#ifndef VQVS_WS_GELU_IL
+#define VQVS_WS_GELU_IL 1  // 0: the per-element form (A/B measurements)
+#endif
+template <int Q, int N, bool IL>
+__device__ __forceinline__ void ws_gelu_n(float (&v)[N]) {
+  // gelu(v) = v * Phi(v), Phi(v) = clamp01(0.5 + v * p(min(v^2, 16))): inside [-4, 4] this is the polynomial itself; outside, v * p(16)
+  // = v / 8 carries the sum past [0, 1] and the clamp (a free output modifier of the v_fma) saturates Phi at 0 / 1 -- one v_min in
+  // place of the v_med3 on v (VOP3 with two inline constants: twice the issue cost, tools/ubench/valu_mix.hip).
+  float w[N], p[N];
+#define WS_G8(expr)                    \
+  _Pragma("unroll") for (int i = 0; i < N; ++i) { expr; } \
+  if (VQVS_WS_GELU_IL && IL) __builtin_amdgcn_sched_barrier(0);
+  WS_G8(w[i] = v[i] * v[i])
+  WS_G8(w[i] = __builtin_fminf(w[i], 16.0f))
+  if constexpr (Q == GELU_POLY6) {
+    WS_G8(p[i] = fmaf(2.81608722e-08f, w[i], -1.89188380e-06f))
+    WS_G8(p[i] = fmaf(p[i], w[i], 5.41903041e-05f))
+    WS_G8(p[i] = fmaf(p[i], w[i], -8.78980255e-04f))
+    WS_G8(p[i] = fmaf(p[i], w[i], 9.11294959e-03f))
+    WS_G8(p[i] = fmaf(p[i], w[i], -6.53883549e-02f))
+    WS_G8(p[i] = fmaf(p[i], w[i], 3.98526915e-01f))
+  } else {
+    WS_G8(p[i] = fmaf(-1.301278171e-09f, w[i], 1.041951057e-07f))
+    WS_G8(p[i] = fmaf(p[i], w[i], -3.657111166e-06f))
+    WS_G8(p[i] = fmaf(p[i], w[i], 7.485478930e-05f))
+    WS_G8(p[i] = fmaf(p[i], w[i], -1.006488756e-03f))
+    WS_G8(p[i] = fmaf(p[i], w[i], 9.505392772e-03f))
+    WS_G8(p[i] = fmaf(p[i], w[i], -6.588783436e-02f))
+    WS_G8(p[i] = fmaf(p[i], w[i], 3.986733897e-01f))
+  }
+  WS_G8(p[i] = __builtin_amdgcn_fmed3f(fmaf(v[i], p[i], 0.5f), 0.0f, 1.0f))
+  WS_G8(v[i] = v[i] * p[i])
+#undef WS_G8
+}
+
+// (per-element form, scheduling left to the compiler: the AVG instantiations, whose four raw rows per chunk set leave no
+//  registers for eight pinned chains)
 template <int Q>
 __device__ __forceinline__ float ws_gelu(float v) {
-  const float vc = __builtin_amdgcn_fmed3f(v, -4.0f, 4.0f);
-  const float w = vc * vc;
+  const float w = __builtin_fminf(v * v, 16.0f);
   float p;
   if constexpr (Q == GELU_POLY6) {
     p = fmaf(2.81608722e-08f, w, -1.89188380e-06f);
@@ -65,7 +104,7 @@ __device__ __forceinline__ float ws_gelu(float v) {
     p = fmaf(p, w, -6.588783436e-02f);
     p = fmaf(p, w, 3.986733897e-01f);
   }
-  return v * fmaf(vc, p, 0.5f);
+  return v * __builtin_amdgcn_fmed3f(fmaf(v, p, 0.5f), 0.0f, 1.0f);
 }
 
 // A K segment of the launch (kernels.hpp SegDesc, plus the identity-skip pseudo-segment), as the kernel wants it.  The waves keep
@@ -207,7 +246,8 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
       u32x4 a0, a1;
       u32x4 b0, b1;   // AVG: the second source row of each staged row
       unsigned meta;  // bit 0: prologue, bit 1 / 2: row 0 / 1 inside the clip (outside: the convolution's zero padding),
-                      // bit 3: identity segment, bit 4: avg-pooled segment, bits 8..: the identity segment's chunk index
+                      // bit 3: identity segment, bit 4: avg-pooled segment, bit 5: some staged row of this tile lies outside the clip
+                      // (wave-uniform: only then are the zero masks applied), bits 8..: the identity segment's chunk index
       int ssaddr;     // LDS byte address of this thread's eight (scale, shift) pairs
     };
     Raw R0, R1, R2;
@@ -232,7 +272,7 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
     };
     SegF nx = fetch(0);
     Prep cur;
-    int cur_xf = 0, cur_id = 0, cur_idch = 0, cur_avg = 0;  // (wave-uniform parts of meta, kept scalar)
+    int cur_xf = 0, cur_id = 0, cur_idch = 0, cur_avg = 0, cur_edge = 0;  // (wave-uniform parts of meta, kept scalar)
     int ss_clip = -1;  // clip whose (scale, shift) table was written last
     unsigned cur_valid = 0;
     auto refresh_ss = [&]() {
@@ -271,6 +311,7 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
       cur_id = f.ntaps == 0 ? 1 : 0;
       cur_idch = 0;
       cur_valid = ((tm0 >= 0 && tm0 < L) ? 2u : 0u) | ((tm1 >= 0 && tm1 < L) ? 4u : 0u);
+      cur_edge = (lt.tx * a.TTO - f.dil < 0 || lt.tx * a.TTO - f.dil + 256 > L) ? 1 : 0;
       lnch = f.nch;
       nx = fetch(lseg + 1 == a.nseg ? 0 : lseg + 1);
     };
@@ -278,7 +319,7 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
     sync_lds();  // (the first clip's (scale, shift) table is visible to every producer wave; the consumers match this barrier)
     auto prepare = [&]() -> Prep {
       Prep pr = cur;
-      pr.meta = cur_valid | (unsigned)(cur_xf | (cur_id << 3) | (cur_avg << 4) | (cur_idch << 8));
+      pr.meta = cur_valid | (unsigned)(cur_xf | (cur_id << 3) | (cur_avg << 4) | (cur_edge << 5) | (cur_idch << 8));
       if (VQVS_WS_EXP & 2048) {  // ablation (valid for a single 64-channel segment only): the cheapest possible cursor
         ++issued;
         const int adv = (issued & 1) ? 64 : a.TTO * 128 - 64;
@@ -347,7 +388,19 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
       else
         asm volatile("s_waitcnt vmcnt(4)" : "+v"(r.a0), "+v"(r.a1));
     };
-    auto xform8 = [&](u32x4 raw, const f32x4& s0, const f32x4& s1, const f32x4& s2, const f32x4& s3) -> u32x4 {
+    auto affine8 = [&](u32x4 raw, const f32x4& s0, const f32x4& s1, const f32x4& s2, const f32x4& s3, float (&u)[8]) {
+      const V8 h = __builtin_bit_cast(V8, raw);
+      u[0] = fmaf((float)h[0], s0[0], s0[1]);
+      u[1] = fmaf((float)h[1], s0[2], s0[3]);
+      u[2] = fmaf((float)h[2], s1[0], s1[1]);
+      u[3] = fmaf((float)h[3], s1[2], s1[3]);
+      u[4] = fmaf((float)h[4], s2[0], s2[1]);
+      u[5] = fmaf((float)h[5], s2[2], s2[3]);
+      u[6] = fmaf((float)h[6], s3[0], s3[1]);
+      u[7] = fmaf((float)h[7], s3[2], s3[3]);
+      if (VQVS_WS_GELU_IL) __builtin_amdgcn_sched_barrier(0);
+    };
+    auto xform8_plain = [&](u32x4 raw, const f32x4& s0, const f32x4& s1, const f32x4& s2, const f32x4& s3) -> u32x4 {
       const V8 h = __builtin_bit_cast(V8, raw);
       V8 o;
       o[0] = (T)ws_gelu<GQ>(fmaf((float)h[0], s0[0], s0[1]));
@@ -369,6 +422,19 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
       WS_AVG1(4, s2[0], s2[1]) WS_AVG1(5, s2[2], s2[3]) WS_AVG1(6, s3[0], s3[1]) WS_AVG1(7, s3[2], s3[3])
 #undef WS_AVG1
       return __builtin_bit_cast(u32x4, o);
+    };
+    auto xform8 = [&](u32x4 raw, const f32x4& s0, const f32x4& s1, const f32x4& s2, const f32x4& s3) -> u32x4 {
+      if constexpr (AVG) {
+        return xform8_plain(raw, s0, s1, s2, s3);
+      } else {
+        float u[8];
+        affine8(raw, s0, s1, s2, s3, u);
+        ws_gelu_n<GQ, 8, true>(u);
+        V8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (T)u[i];
+        return __builtin_bit_cast(u32x4, o);
+      }
     };
     auto raw8_avg = [&](u32x4 ra, u32x4 rb) -> u32x4 {
       const V8 h = __builtin_bit_cast(V8, ra), k = __builtin_bit_cast(V8, rb);
@@ -400,8 +466,8 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
         o0 = raw8_avg(r.a0, r.b0);
         o1 = raw8_avg(r.a1, r.b1);
       }
-      if (!(VQVS_WS_EXP & 128)) {
-        // rows outside the clip are the convolution's zero padding: AND with a 0 / ~0 lane mask (v_bfe_i32 + v_and_b32; a
+      if ((um & 32) && !(VQVS_WS_EXP & 128)) {
+        // rows outside the clip are the convolution's zero padding (edge tiles only): AND with a 0 / ~0 lane mask (v_bfe_i32 + v_and_b32; a
         // v_cndmask_b32 on VCC measured ~7x the issue cost of a v_and_b32, tools/ubench/valu_mix.hip)
         const unsigned m0 = (unsigned)__builtin_amdgcn_sbfe((int)r.meta, 1, 1), m1 = (unsigned)__builtin_amdgcn_sbfe((int)r.meta, 2, 1);
 #pragma unroll
@@ -808,11 +874,14 @@ int ws_launch(const WsArgs& w, hipStream_t st) {
 }
 template <typename T>
 int ws_launch_t(const WsArgs& w, int CT, bool res, bool avg, hipStream_t st) {
+  // (no RES && AVG instantiation: resident weights + four loads per chunk do not fit 128 VGPRs, and a spill has no place beside
+  //  the producers' counted waits -- launch_conv_ws never asks for it, tools/check_no_scratch.py gates the rest at build time)
+  if (avg && res) return -1;
   if (CT == 128) {
-    if (avg) return res ? ws_launch<T, 2, true, true>(w, st) : ws_launch<T, 2, false, true>(w, st);
+    if (avg) return ws_launch<T, 2, false, true>(w, st);
     return res ? ws_launch<T, 2, true, false>(w, st) : ws_launch<T, 2, false, false>(w, st);
   }
-  if (avg) return res ? ws_launch<T, 1, true, true>(w, st) : ws_launch<T, 1, false, true>(w, st);
+  if (avg) return ws_launch<T, 1, false, true>(w, st);
   return res ? ws_launch<T, 1, true, false>(w, st) : ws_launch<T, 1, false, false>(w, st);
 }
 
