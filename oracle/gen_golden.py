@@ -267,6 +267,23 @@ def gen_vqvae():
     dec2 = ref_cpu.vqvae_decode(sd, 32, "exp", codes[:, :16], labels, 5, x_T, noises, constrain=True)
     check("vqvae decode 5 steps", dec, dec2, tol=1e-5)
     save("f8_vqvae_decode", x_T_seed=51, noise_seed=52, codes16=codes[:, :16], labels=labels, x0=dec)
+    # F8b: the same decode at BASELINE config 4's step count (50): the 5-step fixture above is dominated by the first reverse
+    # step's 1 / sqrt(alpha_bar(1)) amplification, which 50 steps average out -- the 1e-3 gate of the 2-byte modes is claimed here
+    x_T = seeded((2, 1, 4096), 53)
+    gen = torch.Generator().manual_seed(54)
+    noises = [torch.randn(x_T.shape, generator=gen) for _ in range(50)]
+    it = iter(noises)
+    dmod.torch.randn_like = lambda t, *a, **k: next(it)
+    vmod.torch.randn = lambda *a, **k: x_T.clone()
+    try:
+        with torch.no_grad():
+            dec = model.decode(codes[:, :16], labels, steps=50, constrain=True)
+    finally:
+        dmod.torch.randn_like = orig_rl
+        vmod.torch.randn = orig_r
+    dec2 = ref_cpu.vqvae_decode(sd, 32, "exp", codes[:, :16], labels, 50, x_T, noises, constrain=True)
+    check("vqvae decode 50 steps", dec, dec2, tol=1e-5)
+    save("f8b_vqvae_decode50", x_T_seed=53, noise_seed=54, codes16=codes[:, :16], labels=labels, x0=dec)
 
 
 # ---------------------------------------------------------------- F9 classifier (config 5)

@@ -9,7 +9,7 @@ from oracle import ref_cpu
 from vq_voice_swap_amd import EncoderPredictor, VQVAE
 from vq_voice_swap_amd.det_init import det_init_
 
-from util import rel_rms, rms, seeded
+from util import gate, rel_rms, rms, seeded
 
 
 def make_encpred(num_latents=96):
@@ -79,7 +79,7 @@ def test_encpred_guided_decode_vs_oracle():
     ep.to(dev)
     got = model.decode(codes.to(dev), labels.to(dev), steps=3, constrain=True, enc_pred=ep, enc_pred_scale=scale, x_T=x_T.to(dev),
                        noise=[n.to(dev) for n in noises]).cpu()
-    assert rms(got - want) < 1e-3
+    gate("encoder-predictor-guided vqvae32 decode 3 steps vs oracle (fp32)", got, want, 1e-3)
     assert rms(want - plain) > 10 * rms(got - want), "guidance term too small for the comparison to mean anything"
 
 

@@ -106,6 +106,13 @@ def test_vqvae_paths_match_reference(golden, lib_built):
     noises = [torch.randn(x_T.shape, generator=gen) for _ in range(5)]
     dec = ref_cpu.vqvae_decode(sd, 32, "exp", torch.from_numpy(z8["codes16"]), torch.from_numpy(z8["labels"]), 5, x_T, noises, constrain=True)
     assert (dec - torch.from_numpy(z8["x0"])).abs().max().item() <= 1e-5
+    # 50-step decode (F8b: BASELINE config 4's step count)
+    z8b = golden("f8b_vqvae_decode50")
+    x_T = seeded((2, 1, 4096), int(z8b["x_T_seed"]))
+    gen = torch.Generator().manual_seed(int(z8b["noise_seed"]))
+    noises = [torch.randn(x_T.shape, generator=gen) for _ in range(50)]
+    dec = ref_cpu.vqvae_decode(sd, 32, "exp", torch.from_numpy(z8b["codes16"]), torch.from_numpy(z8b["labels"]), 50, x_T, noises, constrain=True)
+    assert (dec - torch.from_numpy(z8b["x0"])).abs().max().item() <= 1e-5
 
 
 def test_time_embedding_matches_reference(golden, lib_built):

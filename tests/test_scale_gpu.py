@@ -13,7 +13,7 @@ from oracle import ref_cpu
 from vq_voice_swap_amd import DiffusionModel, VQVAE
 from vq_voice_swap_amd.det_init import det_init_
 
-from util import rel_rms, rms, seeded
+from util import gate, rel_rms, rms, seeded
 
 pytestmark = pytest.mark.gpu
 torch.set_num_threads(8)  # same as every other test module: bit-exact CPU checks depend on the thread count
@@ -68,7 +68,7 @@ def test_unet64_ten_step_sample_vs_oracle(dev, unet64):
     for prec in ("fp32", "fp16"):
         model.set_precision(prec)
         got = model.diffusion.ddpm_sample(x_T.to(dev), model.predictor, 10, constrain=True, noise=[n.to(dev) for n in noises]).cpu()
-        assert rms(got - want) < WAVE_RMS, (prec, rms(got - want))
+        gate(f"unet64 10-step constrained sample vs oracle {prec}", got, want, WAVE_RMS)
     model.predictor.invalidate()
 
 
@@ -136,7 +136,7 @@ def test_headline_workload_vs_reference_fixture(golden):
         model.set_precision(prec)
         got = model.diffusion.ddpm_sample(x_T.to(dev), model.predictor, steps, constrain=True, schedule=lambda t: t ** 2,
                                           noise=[n.to(dev) for n in noises]).cpu()
-        assert rms(got - want) < WAVE_RMS, (prec, rms(got - want))
+        gate(f"F6b headline workload (unet64, 50 steps, t**2, constrain, 2 x 64000) {prec}", got, want, WAVE_RMS)
 
 
 def test_fp16_range_guard_trips():

@@ -138,6 +138,7 @@ struct WsArgs {
   int wres_bytes;  // resident-weights form: bytes of all segments' weights
   int ss_bytes;    // bytes of one clip's (scale, shift) table (all prologue segments), ss_ring copies of it live in LDS
   int ss_ring;     // 2 or 4 (power of two): clips whose chunks can be in flight at once
+  int rev;         // 1: the launch walks its tiles from the last to the first (ConvArgs.rev)
 };
 #define WS_SEGF(s, f) ((s) == 0 ? a.seg[0].f : ((s) == 1 ? a.seg[1].f : ((s) == 2 ? a.seg[2].f : a.seg[3].f)))
 
@@ -176,14 +177,18 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
   constexpr int W_BYTES = 3 * CT * 64;
   constexpr int STAGE = ACT_BYTES + W_BYTES;
   constexpr int OP = CT * 4 + 16;         // out-tile pitch in bytes: one LDS row = one PAIR of output rows, a dword per channel (lo = even row)
+  // WPE: the 128-channel tile with resident weights has no room for a whole out-tile (66 KiB next to 96 KiB of weights): every
+  // consumer wave rounds, transposes and stores its own 64 x 64 part through a private 2 KiB region, 16 rows at a time.
+  constexpr bool WPE = RES && WN == 2;
   // streaming form: [stage 0: activations | weights][stage 1][out-tile][statistics]
-  // resident form : [activations 0][activations 1][identity block 0][identity block 1][out-tile][statistics][all weights]
-  constexpr int ACT_STRIDE = RES ? ACT_BYTES : STAGE;      // activation slot s at s * ACT_STRIDE
-  constexpr int WS_OFF = RES ? 2 * ACT_BYTES : ACT_BYTES;  // streamed (or identity) weight slot s at WS_OFF + s * WS_STRIDE
-  constexpr int WS_STRIDE = RES ? CT * 64 : STAGE;
-  constexpr int O_OFF = RES ? 2 * ACT_BYTES + 2 * CT * 64 : 2 * STAGE;
-  constexpr int R_OFF = O_OFF + 128 * OP;  // [4 time quarters][CT][2] partial statistics
-  constexpr int WRES_OFF = R_OFF + 4 * CT * 8;
+  // resident form : [activations 0][activations 1][out-tile, or 8 private regions][statistics][all weights]
+  constexpr int ACT_STRIDE = RES ? ACT_BYTES : STAGE;  // activation slot s at s * ACT_STRIDE
+  constexpr int WS_OFF = ACT_BYTES;                    // streaming form: weight slot s at WS_OFF + s * WS_STRIDE
+  constexpr int WS_STRIDE = STAGE;
+  constexpr int O_OFF = RES ? 2 * ACT_BYTES : 2 * STAGE;
+  constexpr int R_OFF = O_OFF + (WPE ? 8 * 2048 : 128 * OP);  // [4 time quarters][CT][2] partial statistics
+  constexpr int C_OFF = R_OFF + 4 * CT * 8;  // resident form: the 32 x 32 identity block (2 KiB), then 2 KiB of zeros (identity-skip chunks)
+  constexpr int WRES_OFF = C_OFF + (RES ? 4096 : 0);
   const int SS_OFF = WRES_OFF + (RES ? a.wres_bytes : 0);  // per-clip (scale, shift) tables, a.ss_ring of them
   constexpr int GQ = WsOp<T>::gq;
   typedef typename WsOp<T>::v8 V8;
@@ -215,15 +220,26 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
   const int n = a.nchunks;
   const int Q = (te - tb) * n;  // steps of this workgroup
   if (Q <= 0) return;
+  // A reversed launch (a.rev) walks the same ranges from the far end: consecutive launches alternate direction, so each one
+  // starts on the rows its predecessor touched last -- the part of the tensor that is still in the 256 MB Infinity Cache.
   TileCo first;
   {
-    const int rest = tb / a.nty;
-    first.ty = tb - rest * a.nty;
+    const int ft = a.rev ? a.ntiles - 1 - tb : tb;
+    const int rest = ft / a.nty;
+    first.ty = ft - rest * a.nty;
     first.b = rest / a.ntx;
     first.tx = rest - first.b * a.ntx;
   }
   auto next_tile = [&](TileCo& t) {
-    if (++t.ty == a.nty) {
+    if (a.rev) {
+      if (--t.ty < 0) {
+        t.ty = a.nty - 1;
+        if (--t.tx < 0) {
+          t.tx = a.ntx - 1;
+          --t.b;
+        }
+      }
+    } else if (++t.ty == a.nty) {
       t.ty = 0;
       if (++t.tx == a.ntx) {
         t.tx = 0;
@@ -246,8 +262,8 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
       u32x4 a0, a1;
       u32x4 b0, b1;   // AVG: the second source row of each staged row
       unsigned meta;  // bit 0: prologue, bit 1 / 2: row 0 / 1 inside the clip (outside: the convolution's zero padding),
-                      // bit 3: identity segment, bit 4: avg-pooled segment, bit 5: some staged row of this tile lies outside the clip
-                      // (wave-uniform: only then are the zero masks applied), bits 8..: the identity segment's chunk index
+                      // bit 4: avg-pooled segment, bit 5: some staged row of this tile lies outside the clip
+                      // (wave-uniform: only then are the zero masks applied)
       int ssaddr;     // LDS byte address of this thread's eight (scale, shift) pairs
     };
     Raw R0, R1, R2;
@@ -272,7 +288,7 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
     };
     SegF nx = fetch(0);
     Prep cur;
-    int cur_xf = 0, cur_id = 0, cur_idch = 0, cur_avg = 0, cur_edge = 0;  // (wave-uniform parts of meta, kept scalar)
+    int cur_xf = 0, cur_avg = 0, cur_edge = 0;  // (wave-uniform parts of meta, kept scalar)
     int ss_clip = -1;  // clip whose (scale, shift) table was written last
     unsigned cur_valid = 0;
     auto refresh_ss = [&]() {
@@ -308,8 +324,6 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
       }
       cur.ssaddr = SS_OFF + (lt.b & (a.ss_ring - 1)) * a.ss_bytes + f.ss_lds + oct * 64;
       cur_xf = f.ss != nullptr ? 1 : 0;
-      cur_id = f.ntaps == 0 ? 1 : 0;
-      cur_idch = 0;
       cur_valid = ((tm0 >= 0 && tm0 < L) ? 2u : 0u) | ((tm1 >= 0 && tm1 < L) ? 4u : 0u);
       cur_edge = (lt.tx * a.TTO - f.dil < 0 || lt.tx * a.TTO - f.dil + 256 > L) ? 1 : 0;
       lnch = f.nch;
@@ -319,7 +333,7 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
     sync_lds();  // (the first clip's (scale, shift) table is visible to every producer wave; the consumers match this barrier)
     auto prepare = [&]() -> Prep {
       Prep pr = cur;
-      pr.meta = cur_valid | (unsigned)(cur_xf | (cur_id << 3) | (cur_avg << 4) | (cur_edge << 5) | (cur_idch << 8));
+      pr.meta = cur_valid | (unsigned)(cur_xf | (cur_avg << 4) | (cur_edge << 5));
       if (VQVS_WS_EXP & 2048) {  // ablation (valid for a single 64-channel segment only): the cheapest possible cursor
         ++issued;
         const int adv = (issued & 1) ? 64 : a.TTO * 128 - 64;
@@ -340,7 +354,6 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
           cur.off0 += 64;
           cur.off1 += 64;
           cur.ssaddr += 256;
-          cur_idch += cur_id;  // identity segment: chunk index within the channel tile
         }
       }
       return pr;
@@ -478,19 +491,6 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
       }
       *reinterpret_cast<u32x4*>(sb + dst0) = o0;
       *reinterpret_cast<u32x4*>(sb + dst0 + 128 * 64) = o1;
-      if (um & 8) {
-        // identity segment: its "weights" are the identity block for output channels [ch * 32, +32) of the tile, written here
-        // in the DMA image's layout: row j = output channel, 32 k-values (k = skip channel - ch * 32), swizzled octets
-        if (pt < CT * 4) {
-          const int j = pt >> 2;
-          const int dlt = j - (um >> 8) * 32 - oct * 8;  // element e of this octet is 1 iff e == dlt
-          u32x4 bi;
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            bi[e] = (dlt == 2 * e ? (unsigned)WsOp<T>::one : 0u) | (dlt == 2 * e + 1 ? ((unsigned)WsOp<T>::one << 16) : 0u);
-          *reinterpret_cast<u32x4*>(smem + WS_OFF + slot * WS_STRIDE + j * 64 + ((oct ^ ((j >> 2) & 3)) << 4)) = bi;
-        }
-      }
     };
 
     {
@@ -540,19 +540,32 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
     T* const outp = reinterpret_cast<T*>(a.out);
 
     f32x16 acc[2][WN];
-    // LDS byte offset of this lane's B (weight) fragments for k-step 0 / 1: rows tap * CT + wc * WN * 32 + nt * 32 + l31 -- the
+    // LDS byte offset of this lane's B (weight) fragment for k-step 0: rows tap * CT + wc * WN * 32 + nt * 32 + l31 -- the
     // swizzle depends on l31 only, taps and channel tiles are immediate offsets
-    int boff[2];
-    {
-      const int wr = wc * (WN * 32) + l31;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) boff[ks] = wr * 64 + (((ks * 2 + hh) ^ ((wr >> 2) & 3)) << 4);
-    }
+    const int boff = (wc * (WN * 32) + l31) * 64 + ((hh ^ ((l31 >> 2) & 3)) << 4);
     // weight DMA: piece p = 16 rows of 64 B; this lane's row within a piece and its (source-side) swizzled octet
     const int dma_lane = ((lane >> 2) * 32 + (((lane & 3) ^ ((lane >> 4) & 3)) * 8)) * 2;
 
+    // B operand of an identity-segment chunk (unet.py:316: out += skip): the 32 x 32 identity block (k = skip channel, n = output
+    // channel, both relative to the chunk's 32 channels) for the MFMA tile that owns those output channels, a block of zeros for
+    // every other one -- two constant 2 KiB images (rows of 32 k-values, swizzled like the weight rows).  Resident form: written
+    // once, here; streaming form: into the chunk's (otherwise unused) weight slot, one step ahead like a weight DMA.
+    auto write_consts = [&](int off) {
+      if (tid < 128) {
+        const int j = tid >> 2, oct = tid & 3, dlt = j - oct * 8;  // row j: element e of this octet is 1 iff e == dlt
+        u32x4 bi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bi[e] = (dlt == 2 * e ? (unsigned)WsOp<T>::one : 0u) | (dlt == 2 * e + 1 ? ((unsigned)WsOp<T>::one << 16) : 0u);
+        *reinterpret_cast<u32x4*>(smem + off + j * 64 + ((oct ^ ((j >> 2) & 3)) << 4)) = bi;
+      } else if (tid < 256) {
+        *reinterpret_cast<u32x4*>(smem + off + 2048 + (tid - 128) * 16) = u32x4{0u, 0u, 0u, 0u};
+      }
+    };
+    if constexpr (RES) write_consts(C_OFF);
+
     auto dma = [&](int ntaps, int woff, const TileCo& t, int slot) {  // weights of a chunk -> stage `slot`, 1 KiB (16 rows) per wave-instruction
-      if (RES || ntaps == 0 || (VQVS_WS_EXP & 2)) return;  // identity segment: the producers write its identity block
+      if (!RES && ntaps == 0) write_consts(WS_OFF + slot * WS_STRIDE);
+      if (RES || ntaps == 0 || (VQVS_WS_EXP & 2)) return;
       const int wb = woff + t.ty * (CT * 64);
       const int np = ntaps * (CT / 16);
       for (int p = wave; p < np; p += 8) {
@@ -580,6 +593,7 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
       const int t0 = pt_.tx * a.TTO;
       const int nvalid = min(a.TTO, a.Lout - t0);
       const int co0 = pt_.ty * CT;
+      (void)nvalid;
       if (a.stats != nullptr && ltid < CT) {
         const float2* const red = reinterpret_cast<const float2*>(smem + R_OFF);
         float t1 = 0.f, t2 = 0.f;
@@ -592,6 +606,7 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
         float2* o = reinterpret_cast<float2*>(a.stats) + ((size_t)pt_.b * a.ntiles_stat + pt_.tx) * a.Cout + co0 + ltid;
         *o = float2{t1, t2};
       }
+      if constexpr (WPE) return;  // (the rows left with their wave, at the tile's last step)
       // out-tile -> global: a thread takes 8 channels of a row pair (2 x 16 B of LDS), separates the two rows (lo / hi halves of
       // the dwords) and stores 16 B of each; a wave writes whole 2 x CT-byte rows
       constexpr int PPR = CT / 8;  // 8-channel pieces per row
@@ -636,7 +651,8 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
     SegW dw = fetchw(0), dnx = fetchw(a.nseg > 1 ? 1 : 0);
     int d_woff = dw.wbase;
     // LDS byte offset of the weights of the chunk the DMA cursor points at, when it is consumed in a step of parity `par`
-    auto wlds = [&](int par) { return (RES && dw.ntaps != 0) ? WRES_OFF + dw.lds_off + dch * dw.wstep : WS_OFF + par * WS_STRIDE; };
+    // (an identity chunk has no weights: the value is its chunk index within the channel tile)
+    auto wlds = [&](int par) { return dw.ntaps == 0 ? dch : (RES ? WRES_OFF + dw.lds_off + dch * dw.wstep : WS_OFF + par * WS_STRIDE); };
     if constexpr (RES) {
       // all weights, once: segment images are contiguous in the packed weights ([chunk][tap][Cout][32], Cout == CT here)
       const int nsg = a.nseg;
@@ -667,7 +683,10 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
     dma_advance();
     float bj[WN];
     int bias_ty = -1;
-    int aoff[3][2], aoff_d = -1;
+    // (k-step 1 = the same address with bit 5 flipped: the swizzle XORs the 16-byte column index.  The WPE instantiation has no
+    //  registers to spare and flips the bit at every use; the others keep both addresses.)
+    constexpr int NKS = WPE ? 1 : 2;
+    int aoff[3][NKS], aoff_d = -1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // first chunk's (or all resident) weights have landed
     sync_all();
     WS_TMARK(4)
@@ -702,27 +721,33 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
       }
       WS_TMARK(1)
       const char* const sb = smem + (g & 1) * ACT_STRIDE;
-      const char* const sw = smem + wb;
       {
-        // (an identity-segment chunk is a 1-tap chunk whose weights are the identity block the producers wrote: rows of the other
-        //  channel tiles are zero, so every wave runs the same code on every chunk)
         if (d != aoff_d) {  // A-fragment offsets of the three taps (swizzled rows: not additive in the tap), rebuilt when the dilation changes
           aoff_d = d;
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
             const int row = wt * 64 + l31 + k * d;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) aoff[k][ks] = row * 64 + (((ks * 2 + hh) ^ ((row >> 2) & 3)) << 4);
+            for (int ks = 0; ks < NKS; ++ks) aoff[k][ks] = (row * 64 + ((hh ^ ((row >> 2) & 3)) << 4)) ^ (ks * 32);
           }
         }
+        // LDS address of this lane's B fragments, per MFMA tile and k-step: the chunk's weights, or for an identity chunk j (= wb)
+        // the identity block where the tile owns output channels [32 j, 32 j + 32) and the zero block elsewhere -- one code path
+        int bad[WN][NKS];  // (k-step 1: bit 5 flipped, as above; every base is a multiple of 64)
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+          for (int ks = 0; ks < NKS; ++ks)
+          bad[nt][ks] = ((ntaps != 0 ? wb + nt * (32 * 64) : ((RES ? C_OFF : WS_OFF + (g & 1) * WS_STRIDE) + (wc * WN + nt == wb ? 0 : 2048) - wc * (WN * 32 * 64))) + boff) ^ (ks * 32);
         auto tap = [&](int k) {
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
-            const V8 a0 = *reinterpret_cast<const V8*>(sb + aoff[k][ks]);
-            const V8 a1 = *reinterpret_cast<const V8*>(sb + aoff[k][ks] + 32 * 64);
+            const int ao = NKS == 2 ? aoff[k][ks % NKS] : (aoff[k][0] ^ (ks * 32));
+            const V8 a0 = *reinterpret_cast<const V8*>(sb + ao);
+            const V8 a1 = *reinterpret_cast<const V8*>(sb + ao + 32 * 64);
 #pragma unroll
             for (int nt = 0; nt < WN; ++nt) {
-              const V8 bf = *reinterpret_cast<const V8*>(sw + k * (CT * 64) + boff[ks] + nt * 32 * 64);
+              const V8 bf = *reinterpret_cast<const V8*>(smem + (NKS == 2 ? bad[nt][ks % NKS] : (bad[nt][0] ^ (ks * 32))) + k * (CT * 64));
               acc[0][nt] = ws_mfma(a0, bf, acc[0][nt]);
               acc[1][nt] = ws_mfma(a1, bf, acc[1][nt]);
             }
@@ -761,6 +786,74 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
               for (int r = 0; r < 16; ++r)
                 if (mt * 32 + (r & 3) + 8 * (r >> 2) >= lim) acc[mt][nt][r] = 0.f;
         }
+        if constexpr (WPE) {
+          // Wave-private epilogue: 16 rows at a time (accumulator registers 4 j .. 4 j + 3 of both row blocks) are rounded in PAIRS
+          // of rows into this wave's 2 KiB region ([8 row pairs][64 channels] dwords), read back as 8-channel pieces of a pair,
+          // un-zipped (v_perm) and stored: a lane writes 16 B of each of two rows, 8 lanes one 128-byte row segment.  LDS
+          // operations of one wave execute in order, so the region needs no barrier.  Statistics: those of the rounded values.
+          char* const priv = smem + O_OFF + wave * 2048 + zl;
+          char* const wr0 = priv + (2 * hh) * 256 + l31 * 4;
+          const int zlane = lane + zl;   // (lane-derived addresses are rebuilt here, not carried through the K loop)
+          const int prw = zlane >> 3;                                                // pair this lane reads back
+          const int rrow = (prw >> 2) * 32 + ((prw >> 1) & 1) * 4 + (prw & 1) * 2;  // its first row within the wave's 64 (+ 8 j)
+          const char* const rd0 = priv + prw * 256 + (zlane & 7) * 32;
+          // buffer stores through a descriptor that ends behind the tile's last valid row: the rows past it (the clip's end, or the
+          // rows the next tile owns) are out of range and dropped by the address check -- no per-lane masks, no branches.  (RES:
+          // one channel tile per launch, so a row is CT * 2 = 256 bytes.)
+          const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(
+              outp + (size_t)ct.b * a.Lout * CT, 0, (t0 + nvalid) * (CT * 2), 0x00020000);
+          const int vo0 = ((t0 + wt * 64 + rrow) * CT + wc * 64 + (zlane & 7) * 8) * 2;
+          float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+              for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                  const int r = 4 * j + 2 * rr;
+                  char* const o0 = wr0 + (mt * 4 + rr) * 256 + nt * 128;
+                  if constexpr (WsOp<T>::one == 0x3C00) {
+                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                    const h2 ones = {(_Float16)1.0f, (_Float16)1.0f};
+                    const h2 pk = {(_Float16)acc[mt][nt][r], (_Float16)acc[mt][nt][r + 1]};
+                    s1[nt] = __builtin_amdgcn_fdot2(pk, ones, s1[nt], false);
+                    s2[nt] = __builtin_amdgcn_fdot2(pk, pk, s2[nt], false);
+                    *reinterpret_cast<h2*>(o0) = pk;
+                  } else {
+                    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+                    const b2 pk = {(__bf16)acc[mt][nt][r], (__bf16)acc[mt][nt][r + 1]};
+                    const float v0 = (float)pk[0], v1 = (float)pk[1];
+                    s1[nt] += v0 + v1;
+                    s2[nt] = fmaf(v0, v0, fmaf(v1, v1, s2[nt]));
+                    *reinterpret_cast<b2*>(o0) = pk;
+                  }
+                }
+            const u32x4 lo = *reinterpret_cast<const u32x4*>(rd0);
+            const u32x4 hi = *reinterpret_cast<const u32x4*>(rd0 + 16);
+            if (!(VQVS_WS_EXP & 4)) {
+              u32x4 e, o;
+              e[0] = __builtin_amdgcn_perm(lo[1], lo[0], 0x05040100u);
+              e[1] = __builtin_amdgcn_perm(lo[3], lo[2], 0x05040100u);
+              e[2] = __builtin_amdgcn_perm(hi[1], hi[0], 0x05040100u);
+              e[3] = __builtin_amdgcn_perm(hi[3], hi[2], 0x05040100u);
+              __builtin_amdgcn_raw_buffer_store_b128(e, rs_o, vo0 + j * (8 * CT * 2), 0, 0);
+              o[0] = __builtin_amdgcn_perm(lo[1], lo[0], 0x07060302u);
+              o[1] = __builtin_amdgcn_perm(lo[3], lo[2], 0x07060302u);
+              o[2] = __builtin_amdgcn_perm(hi[1], hi[0], 0x07060302u);
+              o[3] = __builtin_amdgcn_perm(hi[3], hi[2], 0x07060302u);
+              __builtin_amdgcn_raw_buffer_store_b128(o, rs_o, vo0 + j * (8 * CT * 2) + CT * 2, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // (one piece at a time: overlapped pieces cost more registers than the kernel has)
+          }
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            s1[nt] += __shfl_xor(s1[nt], 32);
+            s2[nt] += __shfl_xor(s2[nt], 32);
+            if (hh == 0) reinterpret_cast<float2*>(smem + R_OFF)[wt * CT + wc * 64 + nt * 32 + l31 + zl] = float2{s1[nt], s2[nt]};
+          }
+        } else {
         // round PAIRS of rows (same channel) into one dword of the out-tile; the statistics are those of the rounded values
         char* const ob = smem + O_OFF + (wt * 32 + 2 * hh) * OP + (wc * (WN * 32) + l31 + zl) * 4;
 #pragma unroll
@@ -791,6 +884,7 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
           s1 += __shfl_xor(s1, 32);
           s2 += __shfl_xor(s2, 32);
           if (hh == 0) reinterpret_cast<float2*>(smem + R_OFF)[wt * CT + wc * (WN * 32) + nt * 32 + l31 + zl] = float2{s1, s2};
+        }
         }
         pt_ = ct;
         pending = true;
@@ -851,9 +945,9 @@ int ws_num_cus() {
 }
 
 template <int WN>
-constexpr int ws_fixed_lds(bool res) {  // LDS bytes besides resident weights
+constexpr int ws_fixed_lds(bool res) {  // LDS bytes besides resident weights and the (scale, shift) ring
   constexpr int CT = 64 * WN;
-  return (res ? 2 * 256 * 64 + 2 * CT * 64 : 2 * (256 * 64 + 3 * CT * 64)) + 128 * (CT * 4 + 16) + 4 * CT * 8;
+  return (res ? 2 * 256 * 64 : 2 * (256 * 64 + 3 * CT * 64)) + (res && WN == 2 ? 8 * 2048 : 128 * (CT * 4 + 16)) + 4 * CT * 8 + (res ? 4096 : 0);
 }
 constexpr int WS_LDS_MAX = 160 * 1024;
 
@@ -965,6 +1059,8 @@ int launch_conv_ws(const ConvArgs& a, int B, int precision, hipStream_t st) {
   w.nty = a.Cout / CT;
   w.ntiles = w.ntx * w.nty * B;
   w.ntiles_stat = a.ntiles;
+  static const int rev_env = getenv("VQVS_WS_REV") ? atoi(getenv("VQVS_WS_REV")) : 1;  // 0: every launch walks forward (A/B measurements)
+  w.rev = rev_env ? a.rev : 0;
   if (w.ntiles <= 0) return 0;
   // resident weights: one channel tile per launch and everything fits the CU's LDS
   static const int res_env = getenv("VQVS_WS_RES") ? atoi(getenv("VQVS_WS_RES")) : 1;  // 0: always stream the weights (A/B measurements)

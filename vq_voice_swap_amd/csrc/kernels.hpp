@@ -76,6 +76,8 @@ struct ConvArgs {
   int nbw;
   const float2* bw_ss;  // [B][bw_ss_stride] forward (scale, shift), column = output channel
   int bw_ss_stride;
+  int rev;  // 1: walk the tiles from the last clip to the first (consecutive launches alternate: a launch starts on what its
+            // predecessor wrote last, which is what the Infinity Cache still holds); results do not depend on it
 };
 
 int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st);

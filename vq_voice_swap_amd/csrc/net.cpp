@@ -421,6 +421,7 @@ class Builder {
     for (auto& s : segs) desc += (desc.empty() ? "" : "+") + std::to_string(s.C) + "x" + std::to_string(s.ntaps) + (s.resize == RESIZE_AVG2 ? "v" : s.resize == RESIZE_UP2 ? "^" : "") + (s.ntaps == 3 && s.dil > 1 ? "d" + std::to_string(s.dil) : "");
     desc += "->" + std::to_string(Cout) + " L>>" + std::to_string(out.lshift) + (skip ? " +id" : "");
     m_->meta.push_back({"conv", desc, conv_elems, conv_f32, conv_flops});
+    const int rev = (conv_seq_++) & 1;  // consecutive convolutions walk their tiles in opposite directions (ConvArgs.rev)
     m_->add_op([=](const RunCtx& c) -> int {
       ConvArgs a{};
       a.nseg = (int)S.size();
@@ -458,6 +459,7 @@ class Builder {
       a.stats = O.has_stats ? self->statp(O.stats_off) : nullptr;
       a.ntiles = ntiles_of(a.Lout, tile_rows);
       a.tile_rows = tile_rows;
+      a.rev = rev;
       if (has_fuse) {
         a.nbw = (int)F.xf.size();
         int c0 = 0;
@@ -777,6 +779,7 @@ class Builder {
   std::map<std::string, int> pidx_;
   int es_, maxB_, maxL_;
   int next_id_ = 0;
+  int conv_seq_ = 0;
   std::map<int, size_t> sizes_, offs_;
   std::map<int, int> refs_;
   std::map<int, int> tile_rows_;  // rows per statistics tile of each tensor (set by its producer)
