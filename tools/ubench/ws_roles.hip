@@ -37,7 +37,9 @@ __device__ __forceinline__ u32x4 xform8(u32x4 raw, f32x4 s0, f32x4 s1, f32x4 s2,
 }
 
 // MODE bit 0: producers work, bit 1: consumers work, bit 2: barrier per iteration.  NP = producer items per iteration (2 = one chunk)
-template <int MODE, int NP>
+// CM (consumer variant): 0 = as in the kernel, 1 = accumulators in AGPRs, 2 = MFMAs on register operands (no fragment reads),
+// 3 = fragment reads only (no MFMAs), 4 = AGPR accumulators on register operands
+template <int MODE, int NP, int CM = 0>
 __global__ __launch_bounds__(1024) void k(float* out, int iters, float seed) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -86,13 +88,32 @@ __global__ __launch_bounds__(1024) void k(float* out, int iters, float seed) {
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
             const int ao = row * 64 + (((ks * 2 + hh) ^ swz) << 4);
-            const f16x8 x0 = *reinterpret_cast<const f16x8*>(sb + ao);
-            const f16x8 x1 = *reinterpret_cast<const f16x8*>(sb + ao + 2048);
+            f16x8 x0, x1;
+            if (CM == 2 || CM == 4) {
+              x0 = __builtin_bit_cast(f16x8, u32x4{(unsigned)ao, 0x3c003c00u, 0x38003800u, 0x34003400u});
+              x1 = __builtin_bit_cast(f16x8, u32x4{0x3c003c00u, (unsigned)ao, 0x38003800u, 0x34003400u});
+              asm volatile("" : "+v"(x0), "+v"(x1));
+            } else {
+              x0 = *reinterpret_cast<const f16x8*>(sb + ao);
+              x1 = *reinterpret_cast<const f16x8*>(sb + ao + 2048);
+            }
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-              const f16x8 bf = *reinterpret_cast<const f16x8*>(wk + boff[ks] + nt * 2048);
-              acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x0, bf, acc[0][nt], 0, 0, 0);
-              acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x1, bf, acc[1][nt], 0, 0, 0);
+              f16x8 bf;
+              if (CM == 2 || CM == 4) {
+                bf = x1;
+              } else {
+                bf = *reinterpret_cast<const f16x8*>(wk + boff[ks] + nt * 2048);
+              }
+              if (CM == 3) {
+                asm volatile("" ::"v"(x0), "v"(x1), "v"(bf));
+              } else if (CM == 1 || CM == 4) {
+                asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[0][nt]) : "v"(x0), "v"(bf));
+                asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[1][nt]) : "v"(x1), "v"(bf));
+              } else {
+                acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x0, bf, acc[0][nt], 0, 0, 0);
+                acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x1, bf, acc[1][nt], 0, 0, 0);
+              }
             }
           }
         }
@@ -107,18 +128,18 @@ __global__ __launch_bounds__(1024) void k(float* out, int iters, float seed) {
   out[blockIdx.x * 1024 + tid] = res;
 }
 
-template <int MODE, int NP>
+template <int MODE, int NP, int CM = 0>
 float run() {
   float* d;
   (void)hipMalloc(&d, 256 * 1024 * 4);
   const int iters = 2000, LDS = 90 * 1024;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k<MODE, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k<MODE, NP, CM>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
-  hipLaunchKernelGGL((k<MODE, NP>), dim3(256), dim3(1024), LDS, 0, d, 10, 1.0f);
+  hipLaunchKernelGGL((k<MODE, NP, CM>), dim3(256), dim3(1024), LDS, 0, d, 10, 1.0f);
   (void)hipEventRecord(e0);
-  hipLaunchKernelGGL((k<MODE, NP>), dim3(256), dim3(1024), LDS, 0, d, iters, 1.0f);
+  hipLaunchKernelGGL((k<MODE, NP, CM>), dim3(256), dim3(1024), LDS, 0, d, iters, 1.0f);
   (void)hipEventRecord(e1);
   (void)hipEventSynchronize(e1);
   float ms;
@@ -132,5 +153,11 @@ int main() {
   printf("  no barrier : producers alone %7.1f ns   consumers alone %7.1f ns   both %7.1f ns\n", run<1, 2>(), run<2, 2>(), run<3, 2>());
   printf("  s_barrier  : producers alone %7.1f ns   consumers alone %7.1f ns   both %7.1f ns\n", run<5, 2>(), run<6, 2>(), run<7, 2>());
   printf("  producers with twice the arithmetic: alone %7.1f ns   both (barrier) %7.1f ns\n", run<5, 4>(), run<7, 4>());
+  printf("consumer variants (s_barrier): consumers alone / both\n");
+  printf("  as in the kernel            %7.1f %7.1f\n", run<6, 2, 0>(), run<7, 2, 0>());
+  printf("  accumulators in AGPRs       %7.1f %7.1f\n", run<6, 2, 1>(), run<7, 2, 1>());
+  printf("  MFMAs on register operands  %7.1f %7.1f\n", run<6, 2, 2>(), run<7, 2, 2>());
+  printf("  fragment reads only         %7.1f %7.1f\n", run<6, 2, 3>(), run<7, 2, 3>());
+  printf("  AGPRs + register operands   %7.1f %7.1f\n", run<6, 2, 4>(), run<7, 2, 4>());
   return 0;
 }

@@ -774,6 +774,7 @@ int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st) {
     const int r = launch_conv_ws(a, B, precision, st);  // the 2-byte modes' common shapes run on the wave-specialised kernel
     if (r != 0) return r < 0 ? r : 0;
   }
+  if (a.gn != nullptr) VQVS_FAIL(-1, "conv: a fused GroupNorm is only taken where ws_fuses_gn() says so (Cout=%d)", a.Cout);
   if (a.tile_rows != conv_tile_rows(dmax, a.Cout, precision)) VQVS_FAIL(-1, "conv: tile_rows %d does not match dilation %d", a.tile_rows, dmax);
   if (precision == 0) return launch_p<float, true>(a, B, st, wide, big_halo, dmax);
   if (precision == 2) return launch_p<half_t, false>(a, B, st, wide, big_halo, dmax);

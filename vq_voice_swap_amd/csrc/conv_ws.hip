@@ -126,7 +126,23 @@ struct WsSeg {
   int wbase, wstep;  // byte offset of chunk 0's packed weights [tap][Cout][32], bytes per chunk
   int lds_off;       // resident-weights form: byte offset of chunk 0's image in the resident block
 };
+// GroupNorm (+FiLM) coefficients built inside the convolution that reads them (kernels.hpp ConvArgs.gn, GnArgs) -- by the CONSUMER
+// waves, at the first step of a clip (their accumulators are dead there) for a clip that the producers will reach ss_ring / 2 clips
+// later: every thread takes one channel of the concatenated prologue input, adds its tile partials in tile order (fp64), the
+// channels of a group are combined by an xor butterfly over `cpg` lanes (a power of two, groups never straddle a wave), and the
+// (scale, shift) pair goes straight into the LDS table the prologue reads.  Same formulas as gn_prepare_kernel (misc_kernels.hip; reference unet.py:311-314, 345-349).
+struct WsGn {
+  const float *part0, *part1;  // [B][ntiles][C][2] of the (one or two) sources
+  int ntiles0, ntiles1, C0, C1;
+  int nsrc, Ctot, cpg, nclips;
+  double inv_count;
+  const float *gamma, *beta, *film;
+  int film_stride, film_off;
+  unsigned* status;
+  int guard;
+};
 struct WsArgs {
+  WsGn gn;  // gn.nsrc == 0: the (scale, shift) rows come from seg[].ss
   WsSeg seg[4];
   int nseg, nchunks;  // segments (incl. the identity one), chunks per tile (>= 2)
   const void* w;
@@ -149,7 +165,7 @@ struct TileCo {
 #ifndef VQVS_WS_EXP
 #define VQVS_WS_EXP 0  // ablation bits for tools/experiments (results are WRONG when non-zero): 1 no activation loads, 2 no weight DMA,
 #endif                // 4 no tile store, 8 no prologue arithmetic, 16 no MFMA loop, 32 no tile-end statistics / rounding, 64 constant
-                      // (scale, shift), 128 no zero masks, 256 store at the step's start, 1024 idle consumers, 2048 trivial load cursor
+                      // (scale, shift), 128 no zero masks, 256 store at the step's start, 1024 idle consumers, 2048 trivial load cursor, 4096 fragment reads without MFMAs
 
 #ifdef VQVS_TIMING
 __device__ unsigned long long g_ws_timing[32];
@@ -296,6 +312,7 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
       // them with ds_read instead of four more global loads per chunk and thread.  Slot b % ring: chunks of at most `ring`
       // clips are in flight (host: ring = 4 when a clip can take fewer than four steps).
       char* const tab = smem + SS_OFF + (lt.b & (a.ss_ring - 1)) * a.ss_bytes;
+      if (a.gn.nsrc > 0) return;  // (the consumers build the tables of a launch with a fused GroupNorm)
       for (int sg = 0; sg < a.nseg; ++sg) {
         const WsSeg& g = a.seg[sg];
         if (g.ss == nullptr) continue;
@@ -562,6 +579,47 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
       }
     };
     if constexpr (RES) write_consts(C_OFF);
+    auto gn_table = [&](int b) {
+      if (b < 0 || b >= a.gn.nclips) return;
+      char* const tab = smem + SS_OFF + (b & (a.ss_ring - 1)) * a.ss_bytes;
+      for (int c = tid; c < a.gn.Ctot; c += 512) {  // (Ctot and C0 are multiples of 64: a wave stays whole and inside one source)
+        const bool second = c >= a.gn.C0;
+        const int cl = second ? c - a.gn.C0 : c;
+        const int nt = second ? a.gn.ntiles1 : a.gn.ntiles0, Cs = second ? a.gn.C1 : a.gn.C0;
+        const float* p = (second ? a.gn.part1 : a.gn.part0) + ((size_t)(unsigned)b * (unsigned)nt * (unsigned)Cs + (unsigned)cl) * 2;
+        double s1 = 0.0, s2 = 0.0;
+        unsigned bad = 0;
+        for (int t = 0; t < nt; ++t) {
+          const float2 q = *reinterpret_cast<const float2*>(p + (size_t)t * Cs * 2);
+          s1 += (double)q.x;
+          s2 += (double)q.y;
+          if (!(fabsf(q.x) <= 3.0e38f) || !(q.y <= 3.0e38f)) bad |= 1u;  // (the range guard of gn_prepare_kernel)
+          if (a.gn.guard && q.y >= 9.0e8f) bad |= 2u;
+        }
+        if (bad && a.gn.status) atomicOr(a.gn.status, bad);
+        for (int off = 1; off < a.gn.cpg; off <<= 1) {
+          s1 += __shfl_xor(s1, off);
+          s2 += __shfl_xor(s2, off);
+        }
+        const double mean = s1 * a.gn.inv_count;
+        double var = s2 * a.gn.inv_count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double rstd = 1.0 / sqrt(var + 1e-5);
+        double scale = rstd * (double)a.gn.gamma[c];
+        double shift = (double)a.gn.beta[c] - mean * scale;
+        if (a.gn.film) {
+          const float* f = a.gn.film + (size_t)(unsigned)b * a.gn.film_stride + a.gn.film_off;
+          const double fa = (double)f[c] + 1.0;
+          scale *= fa;
+          shift = shift * fa + (double)f[a.gn.Ctot + c];
+        }
+        *reinterpret_cast<float2*>(tab + c * 8) = float2{(float)scale, (float)shift};
+      }
+    };
+    const int gn_ahead = a.gn.nsrc > 0 ? (a.ss_ring >> 1) * (a.rev ? -1 : 1) : 0;  // clips between a table's construction and its clip
+    int gn_clip = -1;  // clip at whose first step the last table was built
+    if (a.gn.nsrc > 0)
+      for (int i = 0; i < (a.ss_ring >> 1); ++i) gn_table(first.b + (a.rev ? -i : i));
 
     auto dma = [&](int ntaps, int woff, const TileCo& t, int slot) {  // weights of a chunk -> stage `slot`, 1 KiB (16 rows) per wave-instruction
       if (!RES && ntaps == 0) write_consts(WS_OFF + slot * WS_STRIDE);
@@ -677,6 +735,7 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
         d_woff += dw.wstep;
       }
     };
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the first tables of a fused GroupNorm are in LDS: the producers read them next)
     __builtin_amdgcn_s_barrier();  // (pairs with the producers' barrier behind their first (scale, shift) table)
     dma(dw.ntaps, d_woff, nt_, 0);
     int ntaps = dw.ntaps, d = dw.dil, wb = wlds(0);  // current chunk
@@ -696,6 +755,10 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
     }
     for (int g = 0; g < Q; ++g) {
       if (cci == 0) {  // first chunk of a tile
+        if (gn_ahead != 0 && ct.b != gn_clip) {  // ... of a clip: the table of the clip `ss_ring / 2` clips on (its slot is free by now)
+          gn_clip = ct.b;
+          gn_table(ct.b + gn_ahead);
+        }
         if ((VQVS_WS_EXP & 256) && pending) {
           store_tile();
           pending = false;
@@ -748,8 +811,12 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
 #pragma unroll
             for (int nt = 0; nt < WN; ++nt) {
               const V8 bf = *reinterpret_cast<const V8*>(smem + (NKS == 2 ? bad[nt][ks % NKS] : (bad[nt][0] ^ (ks * 32))) + k * (CT * 64));
-              acc[0][nt] = ws_mfma(a0, bf, acc[0][nt]);
-              acc[1][nt] = ws_mfma(a1, bf, acc[1][nt]);
+              if (VQVS_WS_EXP & 4096) {  // ablation: the fragment reads stay, the MFMAs go
+                asm volatile("" ::"v"(a0), "v"(a1), "v"(bf));
+              } else {
+                acc[0][nt] = ws_mfma(a0, bf, acc[0][nt]);
+                acc[1][nt] = ws_mfma(a1, bf, acc[1][nt]);
+              }
             }
           }
         };
@@ -995,7 +1062,31 @@ int ws_timing_read(unsigned long long* out32, int reset) {
 
 // Returns 1 when the launch was taken by the wave-specialised kernel, 0 when the shape is not covered (caller falls back to
 // conv_mfma_kernel), < 0 on error.
+namespace {
+struct WsPlan {
+  WsArgs w;
+  int CT;
+  bool res, avg, gn;
+};
+// The launch as the kernel wants it; false = shape not covered.  plan.gn: a.gn is honoured (the producers build the rows).
+bool ws_plan(const ConvArgs& a, int B, int precision, WsPlan& plan);
+}  // namespace
+
+bool ws_fuses_gn(const ConvArgs& a, int B, int precision) {
+  WsPlan plan;
+  return a.gn != nullptr && ws_plan(a, B, precision, plan) && plan.gn;
+}
+
 int launch_conv_ws(const ConvArgs& a, int B, int precision, hipStream_t st) {
+  WsPlan plan;
+  if (!ws_plan(a, B, precision, plan)) return 0;
+  if (a.gn != nullptr && !plan.gn) return 0;  // (the caller launches gn_prepare and comes back without a.gn)
+  const int rc = precision == 2 ? ws_launch_t<half_t>(plan.w, plan.CT, plan.res, plan.avg, st) : ws_launch_t<bf16_t>(plan.w, plan.CT, plan.res, plan.avg, st);
+  return rc < 0 ? rc : 1;
+}
+
+namespace {
+bool ws_plan(const ConvArgs& a, int B, int precision, WsPlan& plan) {
   if (!ws_enabled() || precision == 0) return 0;
   if (a.Cout % 64 != 0 || a.out_f32 || a.epi_gelu || a.nbw || (a.out_rows != 0 && a.out_rows != a.Lout)) return 0;
   // rows per clip a source must have for a given resize (kernels.hpp RESIZE_*)
@@ -1003,7 +1094,8 @@ int launch_conv_ws(const ConvArgs& a, int B, int precision, hipStream_t st) {
   if (a.skip != nullptr && (a.skip_C != a.Cout || !len_ok(a.skip_resize, a.skip_L) || (long long)a.skip_L * a.skip_C * 2 >= (1LL << 29))) return 0;
   bool avg = a.skip != nullptr && a.skip_resize == RESIZE_AVG2;
   const int CT = a.Cout % 128 == 0 ? 128 : 64;
-  WsArgs w{};
+  plan.w = WsArgs{};
+  WsArgs& w = plan.w;
   int dmax = 0, n = 0;
   for (int s = 0; s < a.nseg; ++s) {
     const SegDesc& g = a.seg[s];
@@ -1070,9 +1162,53 @@ int launch_conv_ws(const ConvArgs& a, int B, int precision, hipStream_t st) {
   if ((CT == 128 ? ws_fixed_lds<2>(false) : ws_fixed_lds<1>(false)) + ss_total > WS_LDS_MAX) return 0;
   // (avg-pooled launches stream their weights: resident weights + four loads per chunk do not fit 128 VGPRs without spills, and
   //  compiler-generated scratch traffic has no place beside the producers' counted waits)
-  const bool res = res_env && !avg && w.nty == 1 && (CT == 128 ? ws_fixed_lds<2>(true) : ws_fixed_lds<1>(true)) + w.wres_bytes + ss_total <= WS_LDS_MAX;
-  const int rc = precision == 2 ? ws_launch_t<half_t>(w, CT, res, avg, st) : ws_launch_t<bf16_t>(w, CT, res, avg, st);
-  return rc < 0 ? rc : 1;
+  if (w.ntiles >= (1 << 24)) return 0;  // (the kernel's tile-range arithmetic is 32-bit)
+  plan.CT = CT;
+  plan.avg = avg;
+  plan.res = res_env && !avg && w.nty == 1 && (CT == 128 ? ws_fixed_lds<2>(true) : ws_fixed_lds<1>(true)) + w.wres_bytes + ss_total <= WS_LDS_MAX;
+  if (plan.res && CT == 128 && (long long)a.Lout * CT * 2 >= (1LL << 31)) return 0;  // (the wave-private epilogue's store descriptor covers one clip)
+  // GroupNorm built by the producers (WsGn): every prologue segment is one whole source of *a.gn, in order; a group is a power of
+  // two of lanes; few enough tile partials per channel that the serial sum at a clip change stays short
+  plan.gn = false;
+  static const int gn_env = getenv("VQVS_WS_GN") ? atoi(getenv("VQVS_WS_GN")) : 1;  // 0: always the gn_prepare launch (A/B measurements)
+  static const int gn_max_tiles = getenv("VQVS_WS_GN_TILES") ? atoi(getenv("VQVS_WS_GN_TILES")) : 8;
+  if (a.gn != nullptr && gn_env) {
+    const GnArgs& g = *a.gn;
+    const int cpg = g.groups > 0 ? g.Ctot / g.groups : 0;
+    bool ok = g.nsrc >= 1 && g.nsrc <= 2 && g.mr == nullptr && cpg >= 1 && cpg <= 64 && (cpg & (cpg - 1)) == 0 && g.Ctot % 64 == 0 &&
+              g.src[0].C % 64 == 0 && g.Ctot * 8 == w.ss_bytes;
+    int si = 0;
+    for (int s = 0; s < a.nseg && ok; ++s) {
+      if (a.seg[s].ss == nullptr) continue;
+      ok = si < g.nsrc && a.seg[s].c0 == 0 && a.seg[s].C == g.src[si].C && a.seg[s].Csrc == g.src[si].C && g.src[si].ntiles <= gn_max_tiles;
+      ++si;
+    }
+    ok = ok && si == g.nsrc;
+    if (ok) {
+      WsGn& G = w.gn;
+      G.nsrc = g.nsrc;
+      G.part0 = g.src[0].partials;
+      G.ntiles0 = g.src[0].ntiles;
+      G.C0 = g.src[0].C;
+      G.part1 = g.nsrc > 1 ? g.src[1].partials : nullptr;
+      G.ntiles1 = g.nsrc > 1 ? g.src[1].ntiles : 0;
+      G.C1 = g.nsrc > 1 ? g.src[1].C : 0;
+      G.nclips = B;
+      G.Ctot = g.Ctot;
+      G.cpg = cpg;
+      G.inv_count = g.inv_count;
+      G.gamma = g.gamma;
+      G.beta = g.beta;
+      G.film = g.film;
+      G.film_stride = g.film_stride;
+      G.film_off = g.film_off;
+      G.status = g.status;
+      G.guard = g.guard;
+      plan.gn = true;
+    }
+  }
+  return true;
 }
+}  // namespace
 
 }  // namespace vqvs

@@ -55,6 +55,7 @@ struct BwActFuse {
   int C, c_begin;
 };
 
+struct GnArgs;
 struct ConvArgs {
   SegDesc seg[3];
   int nseg;
@@ -76,6 +77,10 @@ struct ConvArgs {
   int nbw;
   const float2* bw_ss;  // [B][bw_ss_stride] forward (scale, shift), column = output channel
   int bw_ss_stride;
+  // GroupNorm fused into the consumer (conv_ws.hip refresh_ss): when set, the prologue segments' (scale, shift) rows are NOT read
+  // from seg[].ss but built by the convolution's producers from the tile partials described here (every prologue segment is one
+  // source of *gn, in order, whole).  Only launch_conv_ws honours it, and only where ws_fuses_gn() says so.
+  const GnArgs* gn;
   int rev;  // 1: walk the tiles from the last clip to the first (consecutive launches alternate: a launch starts on what its
             // predecessor wrote last, which is what the Infinity Cache still holds); results do not depend on it
 };
@@ -83,6 +88,8 @@ struct ConvArgs {
 int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st);
 // wave-specialised persistent kernel (conv_ws.hip): 1 = launched, 0 = shape not covered (launch_conv falls back to conv_mfma_kernel), < 0 = error
 int launch_conv_ws(const ConvArgs& a, int B, int precision, hipStream_t st);
+// true when launch_conv_ws would take `a` AND build a.gn's (scale, shift) rows itself (then no gn_prepare launch is needed)
+bool ws_fuses_gn(const ConvArgs& a, int B, int precision);
 int conv_tile_rows(int dmax, int Cout, int precision);
 
 // ----------------------------------------------------------------------------------

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <memory>
 
 namespace vqvs {
@@ -297,7 +298,14 @@ class Builder {
   char* wp(size_t off) const { return m_->d_weights + off; }
 
   // ---- ops ---------------------------------------------------------------------------
-  void add_gn(const std::vector<TensorH>& srcs, const std::string& gn_name, bool film, int film_off, int film_stride,
+  // A GroupNorm whose only consumer is the prologue of ONE convolution can be built by that convolution's producers (conv_ws.hip
+  // WsGn): the link lets the two schedule entries agree at run time -- `fused` (set by add_conv) says whether the convolution
+  // takes it for this batch / length, in which case the gn_prepare entry does nothing.
+  struct GnLink {
+    std::function<bool(const RunCtx&)> fused;
+    std::function<void(const RunCtx&, GnArgs&)> fill;
+  };
+  std::shared_ptr<GnLink> add_gn(const std::vector<TensorH>& srcs, const std::string& gn_name, bool film, int film_off, int film_stride,
               size_t film_misc_off, size_t ss_off, bool want_mr = false, size_t mr_off = 0) {
     int Ctot = 0;
     for (auto& s : srcs) Ctot += s.C;
@@ -312,8 +320,8 @@ class Builder {
     const size_t st_off = status_off();
     const int guard = m_->cfg.precision == VQVS_PREC_F16 ? 1 : 0;
     m_->meta.push_back({"gn_prepare", gn_name + " C=" + std::to_string(Ctot) + " L>>" + std::to_string(lshift), 0, 0, 0});
-    m_->add_op([=](const RunCtx& c) -> int {
-      GnArgs a{};
+    auto link = std::make_shared<GnLink>();
+    link->fill = [=](const RunCtx& c, GnArgs& a) {
       const int L = shiftL(c.Lbase, lshift);
       a.nsrc = (int)S.size();
       for (int i = 0; i < a.nsrc; ++i) a.src[i] = GnSrc{self->statp(S[i].stats_off), ntiles_of(L, SR[i]), S[i].C};
@@ -329,8 +337,14 @@ class Builder {
       a.mr = want_mr ? reinterpret_cast<float2*>(self->ssp(mr_off)) : nullptr;
       a.status = reinterpret_cast<unsigned*>(self->miscp(st_off));
       a.guard = guard;
+    };
+    m_->add_op([=](const RunCtx& c) -> int {
+      if (link->fused && link->fused(c)) return 0;
+      GnArgs a{};
+      link->fill(c, a);
       return launch_gn_prepare(a, c.B, c.st);
     });
+    return link;
   }
 
   // g = gelu(GN(x)) [avg-pooled] written once (deep levels, see XformArgs)
@@ -386,7 +400,8 @@ class Builder {
   // out_lshift: logical output length when it differs from the allocation of `out` (padding rows); epi_gelu: out = skip + gelu(acc).
   // Returns the rows per workgroup tile (= rows per statistics / partial-sum tile of the output).
   int add_conv(const std::vector<SegSpec>& segs, const PackedConv& pk, const std::vector<float>& bias, int Cout, const TensorH& out,
-               const TensorH* skip, int skip_resize, int out_lshift = -1000, bool epi_gelu = false, const BwFuse* fuse = nullptr) {
+               const TensorH* skip, int skip_resize, int out_lshift = -1000, bool epi_gelu = false, const BwFuse* fuse = nullptr,
+               std::shared_ptr<GnLink> gn = nullptr) {
     const size_t hi_off = blob.add(pk.hi.data(), pk.hi.size() * 2);
     const size_t lo_off = m_->cfg.precision == VQVS_PREC_F32 ? blob.add(pk.lo.data(), pk.lo.size() * 2) : 0;
     const size_t bias_off = blob.add(bias.data(), bias.size() * 4);
@@ -422,8 +437,7 @@ class Builder {
     desc += "->" + std::to_string(Cout) + " L>>" + std::to_string(out.lshift) + (skip ? " +id" : "");
     m_->meta.push_back({"conv", desc, conv_elems, conv_f32, conv_flops});
     const int rev = (conv_seq_++) & 1;  // consecutive convolutions walk their tiles in opposite directions (ConvArgs.rev)
-    m_->add_op([=](const RunCtx& c) -> int {
-      ConvArgs a{};
+    auto build = [=](const RunCtx& c, ConvArgs& a) {
       a.nseg = (int)S.size();
       for (int i = 0; i < a.nseg; ++i) {
         SegDesc& g = a.seg[i];
@@ -471,6 +485,27 @@ class Builder {
         a.bw_ss_stride = F.ss_stride;
         a.stats = self->statp(F.part_off);
       }
+    };
+    if (gn) {
+      GnLink* const gl = gn.get();
+      gl->fused = [=](const RunCtx& c) -> bool {
+        ConvArgs a{};
+        build(c, a);
+        GnArgs g{};
+        gl->fill(c, g);
+        a.gn = &g;
+        return ws_fuses_gn(a, c.B, prec);
+      };
+    }
+    m_->add_op([=](const RunCtx& c) -> int {
+      ConvArgs a{};
+      build(c, a);
+      GnArgs g{};
+      if (gn) {
+        gn->fill(c, g);
+        a.gn = &g;
+        if (!ws_fuses_gn(a, c.B, prec)) a.gn = nullptr;  // (then the gn_prepare entry before this one has run)
+      }
       return launch_conv(a, c.B, prec, c.st);
     });
     return tile_rows;
@@ -496,7 +531,9 @@ class Builder {
     // GroupNorm 1 coefficients over the (virtually concatenated) input
     const size_t ss1 = alloc_ss(cin);
     const size_t mr1 = rec ? alloc_ss(cin) : 0;
-    add_gn(ins, pre + "pre_cond.0.0", false, 0, 0, 0, ss1, rec != nullptr, mr1);
+    // (a model with a backward pass keeps every table in memory: no fusion there)
+    auto gn1 = add_gn(ins, pre + "pre_cond.0.0", false, 0, 0, 0, ss1, rec != nullptr, mr1);
+    const bool fuse_gn = rec == nullptr && two_byte;
     // conv 1
     TensorH h1 = new_tensor(cout, out_shift, false, true);
     {
@@ -518,13 +555,14 @@ class Builder {
         cb += t.C;
       }
       const float* b = P(pre + "pre_cond.2.bias");
-      add_conv(segs, pk, std::vector<float>(b, b + cout), cout, h1, nullptr, 0);
+      add_conv(segs, pk, std::vector<float>(b, b + cout), cout, h1, nullptr, 0, -1000, false, nullptr, fuse_gn && !pre_xform1 ? gn1 : nullptr);
       for (auto& t : tmp) release(t);
     }
     // GroupNorm 2 (+FiLM) coefficients
     const size_t ss2 = alloc_ss(cout);
     const size_t mr2 = rec ? alloc_ss(cout) : 0;
-    add_gn({h1}, pre + "pre_cond.3", emb, film_off, film_stride, film_misc_off, ss2, rec != nullptr, mr2);
+    auto gn2 = add_gn({h1}, pre + "pre_cond.3", emb, film_off, film_stride, film_misc_off, ss2, rec != nullptr, mr2);
+    const std::shared_ptr<GnLink> gl2 = fuse_gn && !pre_xform2 ? gn2 : nullptr;
     // conv 2 + skip
     TensorH out = new_tensor(cout, out_shift, false, true);
     {
@@ -554,9 +592,9 @@ class Builder {
           segs.push_back(r);
           cb += t.C;
         }
-        add_conv(segs, pk, bias, cout, out, nullptr, 0);
+        add_conv(segs, pk, bias, cout, out, nullptr, 0, -1000, false, nullptr, gl2);
       } else {  // identity skip (never together with a concatenated input in this topology)
-        add_conv(segs, pk, bias, cout, out, &ins[0], s.resize);
+        add_conv(segs, pk, bias, cout, out, &ins[0], s.resize, -1000, false, nullptr, gl2);
       }
       if (pre_xform2) release(g2);
     }
