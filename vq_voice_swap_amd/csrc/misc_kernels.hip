@@ -455,7 +455,7 @@ int launch_out_conv(const OutConvArgs& a, int B, int precision, hipStream_t st) 
 }
 
 int launch_gn_prepare(const GnArgs& a, int B, hipStream_t st) {
-  if (a.Ctot > 1024 || a.groups > 32 || a.Ctot % a.groups) VQVS_FAIL(-1, "gn: unsupported Ctot=%d groups=%d", a.Ctot, a.groups);
+  if (a.Ctot > 2048 || a.groups > 32 || a.Ctot % a.groups) VQVS_FAIL(-1, "gn: unsupported Ctot=%d groups=%d", a.Ctot, a.groups);
   int split = GN_SPLIT;
   while (split > 1 && (a.groups % split || (a.groups / split) * (a.Ctot / a.groups) > 256)) split >>= 1;
   if ((a.groups / split) * (a.Ctot / a.groups) > 256 && a.Ctot > 256) split = a.groups;  // one group per workgroup

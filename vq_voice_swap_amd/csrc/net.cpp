@@ -939,8 +939,10 @@ static int check_cfg(const vqvs_cfg& c) {
     if (c.rb_emb_channels % 64) VQVS_FAIL(VQVS_ERR_ARG, "resblock emb channels must be a multiple of 64");
     return 0;
   }
-  // the reference's configurations are 32 and 64; wider bases would need GroupNorm over > 1024 concatenated channels
-  if (c.base_channels != 32 && c.base_channels != 64) VQVS_FAIL(VQVS_ERR_ARG, "base_channels must be 32 or 64 (got %d)", c.base_channels);
+  // the reference accepts any width (models/unet.py:17-30); here: powers of two from 32 to 128 (in_conv / out_conv distribute
+  // C / 8 row pieces over a 256-thread workgroup; every convolution works on 32-channel K chunks)
+  if (c.base_channels != 32 && c.base_channels != 64 && c.base_channels != 128)
+    VQVS_FAIL(VQVS_ERR_ARG, "base_channels must be 32, 64 or 128 (got %d)", c.base_channels);
   if (c.in_channels != 1) VQVS_FAIL(VQVS_ERR_ARG, "in_channels must be 1 (got %d)", c.in_channels);
   if (c.kind == VQVS_KIND_MFCC_ENCODER) {
     if (c.precision != VQVS_PREC_F32) VQVS_FAIL(VQVS_ERR_ARG, "the MFCC encoder feeds the VQ layer (bit-exact indices): fp32 precision only");

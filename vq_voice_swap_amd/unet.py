@@ -23,15 +23,15 @@ CHANNEL_MULT = (1, 1, 2, 2, 2, 4, 4, 8, 8)
 MIDDLE_DILATIONS = (4, 8, 16, 32)
 
 
-SUPPORTED_BASE_CHANNELS = (32, 64)
+SUPPORTED_BASE_CHANNELS = (32, 64, 128)
 
 
 def check_base_channels(base_channels: int) -> None:
-    """The native schedule is built for the reference's two published widths; the reference itself accepts any
+    """The native schedule covers the reference's two published widths and 128; the reference itself accepts any
     `base_channels` (models/unet.py:17-30).  Fail here, with the reason, rather than at handle creation."""
     if base_channels not in SUPPORTED_BASE_CHANNELS:
         raise ValueError(f"base_channels={base_channels}: the gfx950 library supports {SUPPORTED_BASE_CHANNELS} "
-                         "(GroupNorm blocks wider than 1024 channels are not built); see INTEGRATION.md")
+                         "(in_conv / out_conv need a power-of-two width, every convolution 32-channel chunks); see INTEGRATION.md")
 
 
 
