@@ -128,8 +128,10 @@ int vqvs_resblock_forward(vqvs_model* m, const float* d_x, const float* d_emb, f
 
 /* Range guard: the device status word of a handle, read and cleared (synchronises the device).  Bit 0: a GroupNorm partial sum
  * was not finite -- an activation overflowed the storage type (fp16: 65504) or the input held NaN; bit 1 (VQVS_PREC_F16 only):
- * a 256-row tile's sum of squares reached 9e8, i.e. an activation may have passed 3e4.  The reference (fp32 throughout,
- * unet.py:337-349) has no such limit, so a caller that sees a non-zero word must re-run in VQVS_PREC_F32. */
+ * a 256-row tile's sum of squares reached 9e8, i.e. an activation may have passed 3e4 -- or the tile's RMS ~1.9e3, which fp16
+ * still holds: advisory.  The reference (fp32 throughout, unet.py:337-349) has no such limit, so a caller that sees bit 0 must
+ * re-run in VQVS_PREC_F32.  Only tensors that feed a GroupNorm are observed.  The call waits for the whole device
+ * (hipDeviceSynchronize), whatever stream the forwards ran on. */
 int vqvs_model_status(vqvs_model* m, unsigned* h_status);
 
 /* ---- classifier guidance (BASELINE config 5) -------------------------------------

@@ -269,6 +269,18 @@ def test_decode_uncond_guidance_vs_golden(golden, dev):
                                            constrain=True, vq_scale=vq_scale, label_scale=label_scale, x_T=x_T.to(dev), noise=noises).cpu()
         gate(f"F11 decode_uncond_guidance 4 steps, decoder mode {prec} (predictor promoted to fp32)", got, want, WAVE_RMS)
     assert model.predictor.precision == "fp16"  # the promotion is per call: the decoder's own mode is untouched
+    # ... and so is its device handle: the fp32 handle of the guided call lives beside it (precision_override), nothing is rebuilt
+    model.predictor(x_T.to(dev), torch.full((2,), 0.5, device=dev), cond=model.vq.embed(torch.from_numpy(z["codes"]).to(dev)),
+                    labels=torch.from_numpy(z["labels"]).to(dev))
+    own = model.predictor._handle
+    assert own is not None
+    model.decode_uncond_guidance(torch.from_numpy(z["codes"]).to(dev), torch.from_numpy(z["labels"]).to(dev), steps=2, constrain=True,
+                                 vq_scale=vq_scale, label_scale=label_scale, x_T=x_T.to(dev), noise=noises[:2])
+    assert model.predictor._handle is own and model.predictor.precision == "fp16"
+    alt = model.predictor._alt_handles["fp32"][0]
+    model.decode_uncond_guidance(torch.from_numpy(z["codes"]).to(dev), torch.from_numpy(z["labels"]).to(dev), steps=2, constrain=True,
+                                 vq_scale=vq_scale, label_scale=label_scale, x_T=x_T.to(dev), noise=noises[:2])
+    assert model.predictor._alt_handles["fp32"][0] is alt  # the guided call's fp32 handle is reused, not rebuilt
 
 
 def test_decode_uncond_guidance_50_steps_vs_golden(golden, dev):

@@ -400,6 +400,7 @@ int vqvs_model_status(vqvs_model* m, unsigned* h_status) {
   *h_status = 0;
   if (m->status_misc_off == (size_t)-1) return 0;
   unsigned* d = reinterpret_cast<unsigned*>(reinterpret_cast<float*>(m->d_arena + m->misc_off) + m->status_misc_off);
+  VQVS_HIP(hipDeviceSynchronize());  // (forwards run on the caller's stream; a blocking copy on the null stream alone does not wait for a non-blocking one)
   VQVS_HIP(hipMemcpy(h_status, d, sizeof(unsigned), hipMemcpyDeviceToHost));
   if (*h_status) VQVS_HIP(hipMemset(d, 0, sizeof(unsigned)));
   return 0;

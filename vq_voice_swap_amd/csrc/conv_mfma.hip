@@ -24,6 +24,8 @@
 //                tile statistics for the next GroupNorm (or its backward), one rounding to the storage type, coalesced stores.
 #include <cstdlib>
 
+#include <atomic>
+
 #include "kernels.hpp"
 
 // Optional in-kernel phase timing (tools/conv_phases.py; build with -DVQVS_TIMING into a separate library):
@@ -678,11 +680,13 @@ template <typename T, bool X3, int WN, int HALO, bool SKIPV, int WGN, int WM, bo
 int launch_o(const ConvArgs& a, int B, hipStream_t st) {
   constexpr int LDS = lds_bytes<X3, WN, HALO, WGN, WM>();
   static_assert(LDS <= 160 * 1024, "LDS budget");
-  static bool attr_done = false;
-  if (!attr_done) {
+  static std::atomic<bool> attr_done[64];  // (function attributes are per device: keyed by the current one)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!attr_done[dev].load(std::memory_order_acquire)) {
     VQVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<T, X3, WN, HALO, SKIPV, WGN, WM, DMA, BWF>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_done = true;
+    attr_done[dev].store(true, std::memory_order_release);
   }
   dim3 grid((a.Lout + a.tile_rows - 1) / a.tile_rows, a.Cout / (WGN * WN * 32), B);
   hipLaunchKernelGGL((conv_mfma_kernel<T, X3, WN, HALO, SKIPV, WGN, WM, DMA, BWF>), grid, dim3(256 * WGN), LDS, st, a);

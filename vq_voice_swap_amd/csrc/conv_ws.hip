@@ -16,6 +16,7 @@
 //
 // LDS rows are 64 B (32 channels) with the 16-byte column XOR-swizzled by bits 2..3 of the row, for activations (written by
 // ds_write_b128) and weights (lane-linear DMA image, swizzle applied to the source address) alike: ds_read_b128 conflict-free.
+#include <atomic>
 #include <cstdlib>
 
 #include "kernels.hpp"
@@ -1000,15 +1001,24 @@ int ws_enabled() {
   return v;
 }
 
+// (function attributes and compute-unit counts are per DEVICE: both caches are keyed by the current device, so a process that
+//  drives several GPUs -- not the one-process-per-GPU layout of sampler.py, but allowed by the ABI -- sets them on each)
+constexpr int WS_MAX_DEV = 64;
+int ws_cur_dev() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= WS_MAX_DEV) return 0;
+  return dev;
+}
 int ws_num_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0;
+  static std::atomic<int> n[WS_MAX_DEV];
+  const int dev = ws_cur_dev();
+  int v = n[dev].load(std::memory_order_relaxed);
+  if (v == 0) {
     hipDeviceProp_t p;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 256;
-    n = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+    v = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+    n[dev].store(v, std::memory_order_relaxed);
   }
-  return n;
+  return v;
 }
 
 template <int WN>
@@ -1021,10 +1031,11 @@ constexpr int WS_LDS_MAX = 160 * 1024;
 template <typename T, int WN, bool RES, bool AVG>
 int ws_launch(const WsArgs& w, hipStream_t st) {
   const int lds = ws_fixed_lds<WN>(RES) + (RES ? w.wres_bytes : 0) + w.ss_ring * w.ss_bytes;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static std::atomic<bool> attr_done[WS_MAX_DEV];  // (per instantiation and device; setting it twice from two threads is harmless)
+  const int dev = ws_cur_dev();
+  if (!attr_done[dev].load(std::memory_order_acquire)) {
     VQVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<T, WN, RES, AVG>), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_MAX));
-    attr_done = true;
+    attr_done[dev].store(true, std::memory_order_release);
   }
   static const int grid_env = getenv("VQVS_WS_GRID") ? atoi(getenv("VQVS_WS_GRID")) : 0;  // (A/B measurements: workgroups per launch)
   const int ncu = grid_env > 0 ? grid_env : ws_num_cus();

@@ -137,13 +137,10 @@ class VQVAE(DiffusionModel):
 
             warnings.warn(f"decode_uncond_guidance: the predictor runs in the fp32 mode for this call (decoder mode {prev!r} does not "
                           "meet the 1e-3 waveform contract under guidance extrapolation)", stacklevel=2)
-            self.predictor.set_precision("fp32")
-        try:
+        # (precision_override keeps the decoder's own handle and arena; the fp32 handle is cached beside it for the next call)
+        with self.predictor.precision_override("fp32" if promote else prev):
             out = self.diffusion.ddpm_sample(x_T, pred_fn, steps=steps, progress=progress, constrain=constrain, seed=seed, **kwargs)
             self.predictor.check_status()
-        finally:
-            if promote:
-                self.predictor.set_precision(prev)
         return out
 
     @property
