@@ -736,7 +736,15 @@ int launch_p(const ConvArgs& a, int B, hipStream_t st, bool wide, bool big_halo,
 
 // (128-row tiles with three workgroups per CU were measured 10-25 % slower than 256-row tiles: the per-tile
 // fixed costs double while the SIMDs are already ~70 % busy.)
-int conv_tile_rows(int dmax, int /*Cout*/, int /*precision*/) { return TT_MAX - 2 * dmax; }
+// ws_ok: the launch is one conv_ws_kernel covers for every length (2-byte storage, no fp32 / padded output, no epilogue GELU, no
+// fused backward).  Only such launches may use the 128-row geometry (two 8-wave workgroups per CU), and only at Cout = 64: from
+// 128 output channels on a workgroup's LDS (weights or out-tile) no longer fits twice into a CU; conv_mfma_kernel has no 128-row
+// form at all.  VQVS_WS_ROWS128 = 0 / 1 (A/B measurements).
+int conv_tile_rows(int dmax, int Cout, int precision, bool ws_ok) {
+  static const int on = getenv("VQVS_WS_ROWS128") ? atoi(getenv("VQVS_WS_ROWS128")) : 0;
+  if (on && ws_ok && precision != 0 && Cout == 64 && 128 - 2 * dmax >= 64) return 128 - 2 * dmax;
+  return TT_MAX - 2 * dmax;
+}
 
 #ifdef VQVS_TIMING
 int conv_timing_read(unsigned long long* out16, int reset) {
@@ -779,7 +787,7 @@ int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st) {
     if (r != 0) return r < 0 ? r : 0;
   }
   if (a.gn != nullptr) VQVS_FAIL(-1, "conv: a fused GroupNorm is only taken where ws_fuses_gn() says so (Cout=%d)", a.Cout);
-  if (a.tile_rows != conv_tile_rows(dmax, a.Cout, precision)) VQVS_FAIL(-1, "conv: tile_rows %d does not match dilation %d", a.tile_rows, dmax);
+  if (a.tile_rows != TT_MAX - 2 * dmax) VQVS_FAIL(-1, "conv: tile_rows %d does not match dilation %d (only conv_ws_kernel has a 128-row form)", a.tile_rows, dmax);
   if (precision == 0) return launch_p<float, true>(a, B, st, wide, big_halo, dmax);
   if (precision == 2) return launch_p<half_t, false>(a, B, st, wide, big_halo, dmax);
   return launch_p<bf16_t, false>(a, B, st, wide, big_halo, dmax);

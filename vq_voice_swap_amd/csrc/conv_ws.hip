@@ -187,10 +187,21 @@ __device__ unsigned long long g_ws_timing[32];
 // AVG: the launch has an avg-pooled segment (down-sampling blocks, unet.py:297-303): EVERY chunk then issues four loads per
 // thread (two source rows per staged row; the other segments' second pair is an out-of-range dummy that never reaches memory),
 // so that "the oldest chunk has landed" stays one counted wait.
-template <typename T, int WN, bool RES, bool AVG>
-__global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
-  constexpr int CT = 64 * WN;             // output channels per tile: 2 consumer columns x WN MFMA tiles of 32
-  constexpr int ACT_BYTES = 256 * 64;     // 256 staged rows x 32 channels
+// Geometry (template): ROWS staged rows per tile (256: one workgroup of 16 waves per CU; 128: 8 waves, two workgroups per CU whose
+// barriers, bookkeeping and tile epilogues interleave), CT output channels per tile (32 / 64 / 128).  ROWS / 32 producer waves (a
+// thread stages two rows x eight channels of every chunk) and as many consumer waves, each owning MT x 32 rows by WN x 32 channels.
+template <typename T, int ROWS, int CT, bool RES, bool AVG>
+__global__ __launch_bounds__(ROWS * 4) void conv_ws_kernel(const WsArgs a) {
+  constexpr int WN = CT == 128 ? 2 : 1;   // 32-channel MFMA tiles per consumer wave
+  constexpr int MT = CT == 32 ? 1 : 2;    // 32-row MFMA tiles per consumer wave
+  constexpr int RW = 32 * MT;             // rows per consumer wave
+  constexpr int NWT = ROWS / RW;          // consumer waves along time ...
+  constexpr int NWC = CT == 32 ? 1 : 2;   // ... and along channels
+  constexpr int NCW = NWT * NWC;          // consumer waves = producer waves = ROWS / 32
+  constexpr int NPT = NCW * 64;           // producer threads (= consumer threads)
+  constexpr int HR = ROWS / 2;            // distance between the two rows a producer thread stages
+  constexpr bool DB = CT == 32;           // a tile may be ONE chunk (32 x 3 -> 32): out-tile and statistics are double-buffered
+  constexpr int ACT_BYTES = ROWS * 64;    // staged rows x 32 channels
   constexpr int W_BYTES = 3 * CT * 64;
   constexpr int STAGE = ACT_BYTES + W_BYTES;
   constexpr int OP = CT * 4 + 16;         // out-tile pitch in bytes: one LDS row = one PAIR of output rows, a dword per channel (lo = even row)
@@ -203,8 +214,10 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
   constexpr int WS_OFF = ACT_BYTES;                    // streaming form: weight slot s at WS_OFF + s * WS_STRIDE
   constexpr int WS_STRIDE = STAGE;
   constexpr int O_OFF = RES ? 2 * ACT_BYTES : 2 * STAGE;
-  constexpr int R_OFF = O_OFF + (WPE ? 8 * 2048 : 128 * OP);  // [4 time quarters][CT][2] partial statistics
-  constexpr int C_OFF = R_OFF + 4 * CT * 8;  // resident form: the 32 x 32 identity block (2 KiB), then 2 KiB of zeros (identity-skip chunks)
+  constexpr int O_BYTES = WPE ? NCW * 2048 : (ROWS / 2) * OP;
+  constexpr int R_BYTES = NWT * CT * 8;                  // [NWT time slices][CT][2] partial statistics
+  constexpr int R_OFF = O_OFF + (DB ? 2 : 1) * O_BYTES;
+  constexpr int C_OFF = R_OFF + (DB ? 2 : 1) * R_BYTES;  // resident form: the 32 x 32 identity block (2 KiB), then 2 KiB of zeros (identity-skip chunks)
   constexpr int WRES_OFF = C_OFF + (RES ? 4096 : 0);
   const int SS_OFF = WRES_OFF + (RES ? a.wres_bytes : 0);  // per-clip (scale, shift) tables, a.ss_ring of them
   constexpr int GQ = WsOp<T>::gq;
@@ -270,10 +283,10 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
     asm volatile("" ::: "memory");
   };
 
-  if (wave >= 8) {
+  if (wave >= NCW) {
     // =============================== producers ===============================
-    const int pt = tid - 512;
-    const int oct = pt & 3, r0 = pt >> 2;  // this thread stages rows r0 and r0 + 128, channel octet `oct`, of every chunk
+    const int pt = tid - NPT;
+    const int oct = pt & 3, r0 = pt >> 2;  // this thread stages rows r0 and r0 + HR, channel octet `oct`, of every chunk
     const int dst0 = r0 * 64 + ((oct ^ ((r0 >> 2) & 3)) << 4);
     struct Raw {
       u32x4 a0, a1;
@@ -318,7 +331,7 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
         const WsSeg& g = a.seg[sg];
         if (g.ss == nullptr) continue;
         const char* const row = reinterpret_cast<const char*>(g.ss + (size_t)((unsigned)lt.b * (unsigned)g.ss_stride + (unsigned)g.ss_c0));
-        if (pt * 16 < g.nch * 256) *reinterpret_cast<f32x4*>(tab + g.ss_lds + pt * 16) = *reinterpret_cast<const f32x4*>(row + pt * 16);
+        for (int o = pt * 16; o < g.nch * 256; o += NPT * 16) *reinterpret_cast<f32x4*>(tab + g.ss_lds + o) = *reinterpret_cast<const f32x4*>(row + o);
       }
     };
     auto enter = [&]() {  // the cursor has just moved to (lt, lseg, chunk 0)
@@ -330,10 +343,10 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
       cur.rs[1] = (int)((unsigned)(clip >> 32) & 0xffffu);
       cur.rs[2] = (VQVS_WS_EXP & 2048) ? 0x7fffffff : f.clip_bytes;
       cur.rs[3] = 0x00020000;
-      const int tm0 = lt.tx * a.TTO - f.dil + r0, tm1 = tm0 + 128;  // time of this thread's two rows
+      const int tm0 = lt.tx * a.TTO - f.dil + r0, tm1 = tm0 + HR;  // time of this thread's two rows
       const int sr0 = f.rsz == RESIZE_UP2 ? (tm0 >> 1) : (f.rsz == RESIZE_AVG2 ? 2 * tm0 : tm0);  // (first) source row of row 0
       cur.off0 = (sr0 * f.Csrc + f.c0 + (f.ntaps == 0 ? lt.ty * CT : 0) + oct * 8) * 2;
-      cur.off1 = cur.off0 + (f.rsz == RESIZE_UP2 ? 128 : (f.rsz == RESIZE_AVG2 ? 512 : 256)) * f.Csrc;
+      cur.off1 = cur.off0 + (f.rsz == RESIZE_UP2 ? HR : (f.rsz == RESIZE_AVG2 ? 4 * HR : 2 * HR)) * f.Csrc;
       cur.db = f.rsz == RESIZE_AVG2 ? 2 * f.Csrc : 0x40000000;
       cur_avg = f.rsz == RESIZE_AVG2 ? 1 : 0;
       if (__builtin_expect(lseg == 0 && lt.b != ss_clip, 0)) {
@@ -343,7 +356,7 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
       cur.ssaddr = SS_OFF + (lt.b & (a.ss_ring - 1)) * a.ss_bytes + f.ss_lds + oct * 64;
       cur_xf = f.ss != nullptr ? 1 : 0;
       cur_valid = ((tm0 >= 0 && tm0 < L) ? 2u : 0u) | ((tm1 >= 0 && tm1 < L) ? 4u : 0u);
-      cur_edge = (lt.tx * a.TTO - f.dil < 0 || lt.tx * a.TTO - f.dil + 256 > L) ? 1 : 0;
+      cur_edge = (lt.tx * a.TTO - f.dil < 0 || lt.tx * a.TTO - f.dil + ROWS > L) ? 1 : 0;
       lnch = f.nch;
       nx = fetch(lseg + 1 == a.nseg ? 0 : lseg + 1);
     };
@@ -508,7 +521,7 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
         }
       }
       *reinterpret_cast<u32x4*>(sb + dst0) = o0;
-      *reinterpret_cast<u32x4*>(sb + dst0 + 128 * 64) = o1;
+      *reinterpret_cast<u32x4*>(sb + dst0 + HR * 64) = o1;
     };
 
     {
@@ -552,12 +565,12 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
 #endif
   } else {
     // =============================== consumers ===============================
-    const int wt = wave & 3, wc = wave >> 2;  // time quarter (64 rows), channel half (WN x 32 channels)
+    const int wt = wave % NWT, wc = wave / NWT;  // time slice (RW rows), channel half (WN x 32 channels)
     const int l31 = lane & 31, hh = lane >> 5;
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.w_bytes, 0x00020000);
     T* const outp = reinterpret_cast<T*>(a.out);
 
-    f32x16 acc[2][WN];
+    f32x16 acc[MT][WN];
     // LDS byte offset of this lane's B (weight) fragment for k-step 0: rows tap * CT + wc * WN * 32 + nt * 32 + l31 -- the
     // swizzle depends on l31 only, taps and channel tiles are immediate offsets
     const int boff = (wc * (WN * 32) + l31) * 64 + ((hh ^ ((l31 >> 2) & 3)) << 4);
@@ -583,7 +596,7 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
     auto gn_table = [&](int b) {
       if (b < 0 || b >= a.gn.nclips) return;
       char* const tab = smem + SS_OFF + (b & (a.ss_ring - 1)) * a.ss_bytes;
-      for (int c = tid; c < a.gn.Ctot; c += 512) {  // (Ctot and C0 are multiples of 64: a wave stays whole and inside one source)
+      for (int c = tid; c < a.gn.Ctot; c += NPT) {  // (Ctot and C0 are multiples of 64: a wave stays whole and inside one source)
         const bool second = c >= a.gn.C0;
         const int cl = second ? c - a.gn.C0 : c;
         const int nt = second ? a.gn.ntiles1 : a.gn.ntiles0, Cs = second ? a.gn.C1 : a.gn.C0;
@@ -627,7 +640,7 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
       if (RES || ntaps == 0 || (VQVS_WS_EXP & 2)) return;
       const int wb = woff + t.ty * (CT * 64);
       const int np = ntaps * (CT / 16);
-      for (int p = wave; p < np; p += 8) {
+      for (int p = wave; p < np; p += NCW) {
         const int tap = (p * 16) / CT, colb = p * 16 - tap * CT;
         const int voff = wb + (tap * a.Cout + colb) * 64 + dma_lane;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(smem + WS_OFF + slot * WS_STRIDE + p * 1024), 16, voff, 0, 0, 0);
@@ -645,6 +658,7 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
     // coordinates of the tile whose out-tile sits in LDS (stored at the start of the next step)
     TileCo pt_{0, 0, 0};
     bool pending = false;
+    int obuf = 0, pbuf = 0;  // (DB) buffer the next epilogue writes / the pending tile sits in
     auto store_tile = [&]() {
       int zl = 0;
       asm volatile("" : "+v"(zl));  // (keeps the per-lane address arithmetic of this rare block out of the loop's live registers)
@@ -654,10 +668,10 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
       const int co0 = pt_.ty * CT;
       (void)nvalid;
       if (a.stats != nullptr && ltid < CT) {
-        const float2* const red = reinterpret_cast<const float2*>(smem + R_OFF);
+        const float2* const red = reinterpret_cast<const float2*>(smem + R_OFF + pbuf * R_BYTES);
         float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {  // fixed order: deterministic
+        for (int g = 0; g < NWT; ++g) {  // fixed order: deterministic
           const float2 v = red[g * CT + ltid];
           t1 += v.x;
           t2 += v.y;
@@ -669,12 +683,12 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
       // out-tile -> global: a thread takes 8 channels of a row pair (2 x 16 B of LDS), separates the two rows (lo / hi halves of
       // the dwords) and stores 16 B of each; a wave writes whole 2 x CT-byte rows
       constexpr int PPR = CT / 8;  // 8-channel pieces per row
-      constexpr int PSTEP = 512 / PPR;  // row pairs between this thread's pieces
+      constexpr int PSTEP = NPT / PPR;  // row pairs between this thread's pieces
       const int p0 = ltid / PPR, col = ltid - p0 * PPR;
-      const char* const lsrc = smem + O_OFF + p0 * OP + col * 32;
+      const char* const lsrc = smem + O_OFF + pbuf * O_BYTES + p0 * OP + col * 32;
       T* const gdst = outp + ((size_t)pt_.b * a.Lout + t0 + 2 * p0) * a.Cout + co0 + col * 8;
 #pragma unroll
-      for (int i = 0; i < 128 / PSTEP; ++i) {
+      for (int i = 0; i < (ROWS / 2) / PSTEP; ++i) {
         const int row = 2 * (p0 + i * PSTEP);
         if (row < nvalid) {
           const u32x4 lo = *reinterpret_cast<const u32x4*>(lsrc + i * PSTEP * OP);
@@ -718,7 +732,7 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
       for (int sg = 0; sg < nsg; ++sg) {
         const int np = (WS_SEGF(sg, nch) * WS_SEGF(sg, wstep)) >> 10;
         const int gb = WS_SEGF(sg, wbase), lb = WS_SEGF(sg, lds_off);
-        for (int p = wave; p < np; p += 8)
+        for (int p = wave; p < np; p += NCW)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(smem + WRES_OFF + lb + p * 1024), 16, gb + p * 1024 + dma_lane, 0, 0, 0);
       }
     }
@@ -760,7 +774,7 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
           gn_clip = ct.b;
           gn_table(ct.b + gn_ahead);
         }
-        if ((VQVS_WS_EXP & 256) && pending) {
+        if ((n == 1 || (VQVS_WS_EXP & 256)) && pending) {  // (one-chunk tiles: the previous tile leaves here, from the other buffer)
           store_tile();
           pending = false;
         }
@@ -772,10 +786,9 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
 #pragma unroll
         for (int nt = 0; nt < WN; ++nt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            acc[0][nt][r] = bj[nt];
-            acc[1][nt][r] = bj[nt];
-          }
+          for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt][nt][r] = bj[nt];
       }
       WS_TMARK(0)
       const int nx_ntaps = dw.ntaps, nx_dil = dw.dil, nx_wb = wlds((g + 1) & 1);  // the chunk the DMA cursor points at = the next step's
@@ -790,7 +803,7 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
           aoff_d = d;
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
-            const int row = wt * 64 + l31 + k * d;
+            const int row = wt * RW + l31 + k * d;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) aoff[k][ks] = (row * 64 + ((hh ^ ((row >> 2) & 3)) << 4)) ^ (ks * 32);
           }
@@ -808,7 +821,8 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
           for (int ks = 0; ks < 2; ++ks) {
             const int ao = NKS == 2 ? aoff[k][ks % NKS] : (aoff[k][0] ^ (ks * 32));
             const V8 a0 = *reinterpret_cast<const V8*>(sb + ao);
-            const V8 a1 = *reinterpret_cast<const V8*>(sb + ao + 32 * 64);
+            V8 a1 = a0;
+            if constexpr (MT == 2) a1 = *reinterpret_cast<const V8*>(sb + ao + 32 * 64);
 #pragma unroll
             for (int nt = 0; nt < WN; ++nt) {
               const V8 bf = *reinterpret_cast<const V8*>(smem + (NKS == 2 ? bad[nt][ks % NKS] : (bad[nt][0] ^ (ks * 32))) + k * (CT * 64));
@@ -816,7 +830,7 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
                 asm volatile("" ::"v"(a0), "v"(a1), "v"(bf));
               } else {
                 acc[0][nt] = ws_mfma(a0, bf, acc[0][nt]);
-                acc[1][nt] = ws_mfma(a1, bf, acc[1][nt]);
+                if constexpr (MT == 2) acc[MT - 1][nt] = ws_mfma(a1, bf, acc[MT - 1][nt]);
               }
             }
           }
@@ -833,10 +847,11 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
       // last chunk of the tile: statistics + rounding + out-tile
       if (cci == n - 1 && (VQVS_WS_EXP & 32)) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int nt = 0; nt < WN; ++nt) asm volatile("" ::"v"(acc[mt][nt][0]), "v"(acc[mt][nt][15]));  // keep the MFMAs alive
         pt_ = ct;
+        pbuf = obuf;
         pending = true;
       }
       if (cci == n - 1 && !(VQVS_WS_EXP & 32)) {
@@ -844,10 +859,10 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
         asm volatile("" : "+v"(zl));
         const int t0 = ct.tx * a.TTO;
         const int nvalid = min(a.TTO, a.Lout - t0);
-        const int lim = nvalid - (wt * 64 + 4 * hh) + zl;  // rows of this lane: mt * 32 + (r & 3) + 8 * (r >> 2) < lim are real
-        if (wt * 64 + 64 > nvalid) {
+        const int lim = nvalid - (wt * RW + 4 * hh) + zl;  // rows of this lane: mt * 32 + (r & 3) + 8 * (r >> 2) < lim are real
+        if (wt * RW + RW > nvalid) {
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt)
+          for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < WN; ++nt)
 #pragma unroll
@@ -923,12 +938,12 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
           }
         } else {
         // round PAIRS of rows (same channel) into one dword of the out-tile; the statistics are those of the rounded values
-        char* const ob = smem + O_OFF + (wt * 32 + 2 * hh) * OP + (wc * (WN * 32) + l31 + zl) * 4;
+        char* const ob = smem + O_OFF + obuf * O_BYTES + (wt * (RW / 2) + 2 * hh) * OP + (wc * (WN * 32) + l31 + zl) * 4;
 #pragma unroll
         for (int nt = 0; nt < WN; ++nt) {
           float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt)
+          for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
               char* const o0 = ob + (mt * 16 + ((r & 3) >> 1) + 4 * (r >> 2)) * OP + nt * 128;
@@ -951,10 +966,12 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
             }
           s1 += __shfl_xor(s1, 32);
           s2 += __shfl_xor(s2, 32);
-          if (hh == 0) reinterpret_cast<float2*>(smem + R_OFF)[wt * CT + wc * (WN * 32) + nt * 32 + l31 + zl] = float2{s1, s2};
+          if (hh == 0) reinterpret_cast<float2*>(smem + R_OFF + obuf * R_BYTES)[wt * CT + wc * (WN * 32) + nt * 32 + l31 + zl] = float2{s1, s2};
         }
         }
         pt_ = ct;
+        pbuf = obuf;
+        if constexpr (DB) obuf ^= 1;
         pending = true;
       }
       WS_TMARK(3)
@@ -968,7 +985,7 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(const WsArgs a) {
       // The previous tile's rows leave at the END of its successor's first step, behind the wait for this step's weight DMA: the
       // stores then have a whole step to be acknowledged before the next vmcnt(0) (CDNA counts stores in vmcnt too, and a wait
       // placed right after them exposes the full write latency once per tile).
-      if (pending && cci == (n > 1 ? 1 : 0)) {
+      if (n > 1 && pending && cci == 1) {
         if constexpr (!RES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!(VQVS_WS_EXP & 4)) store_tile();
         pending = false;
@@ -1021,40 +1038,50 @@ int ws_num_cus() {
   return v;
 }
 
-template <int WN>
-constexpr int ws_fixed_lds(bool res) {  // LDS bytes besides resident weights and the (scale, shift) ring
-  constexpr int CT = 64 * WN;
-  return (res ? 2 * 256 * 64 : 2 * (256 * 64 + 3 * CT * 64)) + (res && WN == 2 ? 8 * 2048 : 128 * (CT * 4 + 16)) + 4 * CT * 8 + (res ? 4096 : 0);
+// LDS bytes besides resident weights and the (scale, shift) ring (the kernel's layout constants, restated for the planner)
+constexpr int ws_fixed_lds(int rows, int ct, bool res) {
+  const int ncw = rows / 32, nwt = ct == 32 ? rows / 32 : rows / 64, db = ct == 32 ? 2 : 1;
+  const int obytes = (res && ct == 128) ? ncw * 2048 : (rows / 2) * (ct * 4 + 16);
+  return (res ? 2 * rows * 64 : 2 * (rows * 64 + 3 * ct * 64)) + db * obytes + db * nwt * ct * 8 + (res ? 4096 : 0);
 }
 constexpr int WS_LDS_MAX = 160 * 1024;
+// LDS one workgroup may use: two workgroups of the 128-row geometry share a CU
+constexpr int ws_lds_cap(int rows) { return rows == 256 ? WS_LDS_MAX : WS_LDS_MAX / 2; }
 
-template <typename T, int WN, bool RES, bool AVG>
+template <typename T, int ROWS, int CT, bool RES, bool AVG>
 int ws_launch(const WsArgs& w, hipStream_t st) {
-  const int lds = ws_fixed_lds<WN>(RES) + (RES ? w.wres_bytes : 0) + w.ss_ring * w.ss_bytes;
+  const int lds = ws_fixed_lds(ROWS, CT, RES) + (RES ? w.wres_bytes : 0) + w.ss_ring * w.ss_bytes;
   static std::atomic<bool> attr_done[WS_MAX_DEV];  // (per instantiation and device; setting it twice from two threads is harmless)
   const int dev = ws_cur_dev();
   if (!attr_done[dev].load(std::memory_order_acquire)) {
-    VQVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<T, WN, RES, AVG>), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_MAX));
+    VQVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<T, ROWS, CT, RES, AVG>), hipFuncAttributeMaxDynamicSharedMemorySize, ws_lds_cap(ROWS)));
     attr_done[dev].store(true, std::memory_order_release);
   }
   static const int grid_env = getenv("VQVS_WS_GRID") ? atoi(getenv("VQVS_WS_GRID")) : 0;  // (A/B measurements: workgroups per launch)
-  const int ncu = grid_env > 0 ? grid_env : ws_num_cus();
-  const int grid = w.ntiles < ncu ? w.ntiles : ncu;
-  hipLaunchKernelGGL((conv_ws_kernel<T, WN, RES, AVG>), dim3(grid), dim3(1024), lds, st, w);
+  const int nwg = (grid_env > 0 ? grid_env : ws_num_cus()) * (256 / ROWS);  // persistent workgroups: one (two) per CU
+  const int grid = w.ntiles < nwg ? w.ntiles : nwg;
+  hipLaunchKernelGGL((conv_ws_kernel<T, ROWS, CT, RES, AVG>), dim3(grid), dim3(ROWS * 4), lds, st, w);
   VQVS_HIP(hipGetLastError());
   return 0;
 }
-template <typename T>
-int ws_launch_t(const WsArgs& w, int CT, bool res, bool avg, hipStream_t st) {
+template <typename T, int ROWS, int CT>
+int ws_launch_f(const WsArgs& w, bool res, bool avg, hipStream_t st) {
   // (no RES && AVG instantiation: resident weights + four loads per chunk do not fit 128 VGPRs, and a spill has no place beside
   //  the producers' counted waits -- launch_conv_ws never asks for it, tools/check_no_scratch.py gates the rest at build time)
   if (avg && res) return -1;
-  if (CT == 128) {
-    if (avg) return ws_launch<T, 2, false, true>(w, st);
-    return res ? ws_launch<T, 2, true, false>(w, st) : ws_launch<T, 2, false, false>(w, st);
+  if (avg) return ws_launch<T, ROWS, CT, false, true>(w, st);
+  return res ? ws_launch<T, ROWS, CT, true, false>(w, st) : ws_launch<T, ROWS, CT, false, false>(w, st);
+}
+template <typename T>
+int ws_launch_t(const WsArgs& w, int rows, int CT, bool res, bool avg, hipStream_t st) {
+  if (rows == 128) {  // (two workgroups per CU; 32-channel tiles only come in the 256-row geometry)
+    if (CT == 128) return ws_launch_f<T, 128, 128>(w, res, avg, st);
+    if (CT == 64) return ws_launch_f<T, 128, 64>(w, res, avg, st);
+    return -1;
   }
-  if (avg) return ws_launch<T, 1, false, true>(w, st);
-  return res ? ws_launch<T, 1, true, false>(w, st) : ws_launch<T, 1, false, false>(w, st);
+  if (CT == 128) return ws_launch_f<T, 256, 128>(w, res, avg, st);
+  if (CT == 64) return ws_launch_f<T, 256, 64>(w, res, avg, st);
+  return ws_launch_f<T, 256, 32>(w, res, avg, st);
 }
 
 }  // namespace
@@ -1076,7 +1103,7 @@ int ws_timing_read(unsigned long long* out32, int reset) {
 namespace {
 struct WsPlan {
   WsArgs w;
-  int CT;
+  int CT, rows;
   bool res, avg, gn;
 };
 // The launch as the kernel wants it; false = shape not covered.  plan.gn: a.gn is honoured (the producers build the rows).
@@ -1092,19 +1119,20 @@ int launch_conv_ws(const ConvArgs& a, int B, int precision, hipStream_t st) {
   WsPlan plan;
   if (!ws_plan(a, B, precision, plan)) return 0;
   if (a.gn != nullptr && !plan.gn) return 0;  // (the caller launches gn_prepare and comes back without a.gn)
-  const int rc = precision == 2 ? ws_launch_t<half_t>(plan.w, plan.CT, plan.res, plan.avg, st) : ws_launch_t<bf16_t>(plan.w, plan.CT, plan.res, plan.avg, st);
+  const int rc = precision == 2 ? ws_launch_t<half_t>(plan.w, plan.rows, plan.CT, plan.res, plan.avg, st)
+                                : ws_launch_t<bf16_t>(plan.w, plan.rows, plan.CT, plan.res, plan.avg, st);
   return rc < 0 ? rc : 1;
 }
 
 namespace {
 bool ws_plan(const ConvArgs& a, int B, int precision, WsPlan& plan) {
   if (!ws_enabled() || precision == 0) return 0;
-  if (a.Cout % 64 != 0 || a.out_f32 || a.epi_gelu || a.nbw || (a.out_rows != 0 && a.out_rows != a.Lout)) return 0;
+  if (a.Cout % 32 != 0 || a.out_f32 || a.epi_gelu || a.nbw || (a.out_rows != 0 && a.out_rows != a.Lout)) return 0;
   // rows per clip a source must have for a given resize (kernels.hpp RESIZE_*)
   auto len_ok = [&](int rsz, int Lsrc) { return rsz == RESIZE_UP2 ? Lsrc * 2 == a.Lout : (rsz == RESIZE_AVG2 ? Lsrc / 2 == a.Lout : Lsrc == a.Lout); };
   if (a.skip != nullptr && (a.skip_C != a.Cout || !len_ok(a.skip_resize, a.skip_L) || (long long)a.skip_L * a.skip_C * 2 >= (1LL << 29))) return 0;
   bool avg = a.skip != nullptr && a.skip_resize == RESIZE_AVG2;
-  const int CT = a.Cout % 128 == 0 ? 128 : 64;
+  const int CT = a.Cout % 128 == 0 ? 128 : (a.Cout % 64 == 0 ? 64 : 32);
   plan.w = WsArgs{};
   WsArgs& w = plan.w;
   int dmax = 0, n = 0;
@@ -1148,7 +1176,10 @@ bool ws_plan(const ConvArgs& a, int B, int precision, WsPlan& plan) {
     q.rsz = a.skip_resize;
     n += q.nch;
   }
-  if (a.tile_rows != 256 - 2 * dmax || a.w_bytes > 0x7fffffffLL || n < 2) return 0;
+  // the staged window: 256 rows, or 128 (tile_rows = 128 - 2 dmax, chosen by the schedule builder: conv_tile_rows)
+  const int rows = a.tile_rows == 256 - 2 * dmax ? 256 : (a.tile_rows == 128 - 2 * dmax && CT >= 64 && a.tile_rows > 0 ? 128 : 0);
+  if (rows == 0 || a.w_bytes > 0x7fffffffLL || n < (CT == 32 ? 1 : 2)) return 0;
+  plan.rows = rows;
   w.nchunks = n;
   w.w = a.w_hi;
   w.w_bytes = (int)a.w_bytes;
@@ -1170,13 +1201,13 @@ bool ws_plan(const ConvArgs& a, int B, int precision, WsPlan& plan) {
   if (w.ss_bytes > 8192) return 0;  // (one 16-byte piece per producer thread)
   w.ss_ring = (long long)w.ntx * w.nty * n >= 4 ? 2 : 4;
   const int ss_total = w.ss_ring * w.ss_bytes;
-  if ((CT == 128 ? ws_fixed_lds<2>(false) : ws_fixed_lds<1>(false)) + ss_total > WS_LDS_MAX) return 0;
+  if (ws_fixed_lds(rows, CT, false) + ss_total > ws_lds_cap(rows)) return 0;
   // (avg-pooled launches stream their weights: resident weights + four loads per chunk do not fit 128 VGPRs without spills, and
   //  compiler-generated scratch traffic has no place beside the producers' counted waits)
   if (w.ntiles >= (1 << 24)) return 0;  // (the kernel's tile-range arithmetic is 32-bit)
   plan.CT = CT;
   plan.avg = avg;
-  plan.res = res_env && !avg && w.nty == 1 && (CT == 128 ? ws_fixed_lds<2>(true) : ws_fixed_lds<1>(true)) + w.wres_bytes + ss_total <= WS_LDS_MAX;
+  plan.res = res_env && !avg && w.nty == 1 && ws_fixed_lds(rows, CT, true) + w.wres_bytes + ss_total <= ws_lds_cap(rows);
   if (plan.res && CT == 128 && (long long)a.Lout * CT * 2 >= (1LL << 31)) return 0;  // (the wave-private epilogue's store descriptor covers one clip)
   // GroupNorm built by the producers (WsGn): every prologue segment is one whole source of *a.gn, in order; a group is a power of
   // two of lanes; few enough tile partials per channel that the serial sum at a clip change stays short

@@ -416,7 +416,8 @@ class Builder {
     int dmax = 0;
     for (auto& g : segs)
       if (g.ntaps == 3 && g.dil > dmax) dmax = g.dil;
-    const int tile_rows = conv_tile_rows(dmax, Cout, m_->cfg.precision);
+    const bool ws_ok = !out.f32 && !epi_gelu && fuse == nullptr && out_lshift == -1000;
+    const int tile_rows = conv_tile_rows(dmax, Cout, m_->cfg.precision, ws_ok);
     if (out.has_stats) tile_rows_[out.id] = tile_rows;
     // cost
     double ktot = 0;
