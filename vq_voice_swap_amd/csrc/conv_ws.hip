@@ -40,6 +40,13 @@ template <> struct WsOp<bf16_t> {
   static constexpr unsigned short one = 0x3F80;
   static constexpr int gq = GELU_POLY6;
 };
+// fp32 storage (the parity mode): operands are split x = hi + lo in bf16 and every product is hi*hi + lo*hi + hi*lo in fp32
+// accumulators (drops lo*lo, ~2^-18 relative); the prologue is the exact-erf GELU of common.hpp
+template <> struct WsOp<float> {
+  typedef bf16x8 v8;
+  static constexpr unsigned short one = 0x3F80;
+  static constexpr int gq = GELU_EXACT;
+};
 __device__ __forceinline__ f32x16 ws_mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x16 ws_mfma(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
@@ -147,8 +154,11 @@ struct WsArgs {
   WsSeg seg[4];
   int nseg, nchunks;  // segments (incl. the identity one), chunks per tile (>= 2)
   const void* w;
+  const void* w_lo;  // fp32 storage: the lo plane of the split weights (same packing as w)
   int w_bytes;
   const float* bias;
+  const void* skip;  // fp32 storage: identity-skip source, added in the epilogue (exact) instead of as a K segment
+  int skip_L, skip_rsz;
   void* out;
   float* stats;
   int Cout, Lout, TTO, ntx, nty, ntiles, ntiles_stat;
@@ -201,25 +211,31 @@ __global__ __launch_bounds__(ROWS * 4) void conv_ws_kernel(const WsArgs a) {
   constexpr int NPT = NCW * 64;           // producer threads (= consumer threads)
   constexpr int HR = ROWS / 2;            // distance between the two rows a producer thread stages
   constexpr bool DB = CT == 32;           // a tile may be ONE chunk (32 x 3 -> 32): out-tile and statistics are double-buffered
-  constexpr int ACT_BYTES = ROWS * 64;    // staged rows x 32 channels
-  constexpr int W_BYTES = 3 * CT * 64;
-  constexpr int STAGE = ACT_BYTES + W_BYTES;
+  constexpr bool X3 = sizeof(T) == 4;     // fp32 storage: hi / lo bf16 planes of activations and weights, three MFMAs per product
+  constexpr int ES = (int)sizeof(T);
+  constexpr bool L4 = AVG || X3;          // four loads per thread and chunk (two source rows per staged row, or 32-byte octets)
+  static_assert(!(AVG && X3), "avg-pooled segments are not built for fp32 storage");
+  static_assert(!X3 || (CT == 64 && ROWS == 256), "fp32 storage: 256 x 64 tiles only");
+  constexpr int ACT_BYTES = ROWS * 64;    // staged rows x 32 channels (one bf16 / fp16 plane)
+  constexpr int W_BYTES = 3 * CT * 64;    // ... of weights
+  constexpr int ACT2 = (X3 ? 2 : 1) * ACT_BYTES, W2 = (X3 ? 2 : 1) * W_BYTES;  // [hi plane][lo plane]
+  constexpr int STAGE = ACT2 + W2;
   constexpr int OP = CT * 4 + 16;         // out-tile pitch in bytes: one LDS row = one PAIR of output rows, a dword per channel (lo = even row)
   // WPE: the 128-channel tile with resident weights has no room for a whole out-tile (66 KiB next to 96 KiB of weights): every
   // consumer wave rounds, transposes and stores its own 64 x 64 part through a private 2 KiB region, 16 rows at a time.
-  constexpr bool WPE = RES && WN == 2;
+  constexpr bool WPE = RES && WN == 2 && !X3;
   // streaming form: [stage 0: activations | weights][stage 1][out-tile][statistics]
   // resident form : [activations 0][activations 1][out-tile, or 8 private regions][statistics][all weights]
-  constexpr int ACT_STRIDE = RES ? ACT_BYTES : STAGE;  // activation slot s at s * ACT_STRIDE
-  constexpr int WS_OFF = ACT_BYTES;                    // streaming form: weight slot s at WS_OFF + s * WS_STRIDE
+  constexpr int ACT_STRIDE = RES ? ACT2 : STAGE;  // activation slot s at s * ACT_STRIDE
+  constexpr int WS_OFF = ACT2;                    // streaming form: weight slot s at WS_OFF + s * WS_STRIDE
   constexpr int WS_STRIDE = STAGE;
-  constexpr int O_OFF = RES ? 2 * ACT_BYTES : 2 * STAGE;
-  constexpr int O_BYTES = WPE ? NCW * 2048 : (ROWS / 2) * OP;
+  constexpr int O_OFF = RES ? 2 * ACT2 : 2 * STAGE;
+  constexpr int O_BYTES = X3 ? 0 : (WPE ? NCW * 2048 : (ROWS / 2) * OP);  // (fp32 storage: rows are stored from the accumulators)
   constexpr int R_BYTES = NWT * CT * 8;                  // [NWT time slices][CT][2] partial statistics
   constexpr int R_OFF = O_OFF + (DB ? 2 : 1) * O_BYTES;
   constexpr int C_OFF = R_OFF + (DB ? 2 : 1) * R_BYTES;  // resident form: the 32 x 32 identity block (2 KiB), then 2 KiB of zeros (identity-skip chunks)
   constexpr int WRES_OFF = C_OFF + (RES ? 4096 : 0);
-  const int SS_OFF = WRES_OFF + (RES ? a.wres_bytes : 0);  // per-clip (scale, shift) tables, a.ss_ring of them
+  const int SS_OFF = WRES_OFF + (RES ? (X3 ? 2 : 1) * a.wres_bytes : 0);  // per-clip (scale, shift) tables, a.ss_ring of them
   constexpr int GQ = WsOp<T>::gq;
   typedef typename WsOp<T>::v8 V8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -290,7 +306,7 @@ __global__ __launch_bounds__(ROWS * 4) void conv_ws_kernel(const WsArgs a) {
     const int dst0 = r0 * 64 + ((oct ^ ((r0 >> 2) & 3)) << 4);
     struct Raw {
       u32x4 a0, a1;
-      u32x4 b0, b1;   // AVG: the second source row of each staged row
+      u32x4 b0, b1;   // AVG: the second source row of each staged row; fp32 storage: channels 4..7 of the octet
       unsigned meta;  // bit 0: prologue, bit 1 / 2: row 0 / 1 inside the clip (outside: the convolution's zero padding),
                       // bit 4: avg-pooled segment, bit 5: some staged row of this tile lies outside the clip
                       // (wave-uniform: only then are the zero masks applied)
@@ -345,9 +361,9 @@ __global__ __launch_bounds__(ROWS * 4) void conv_ws_kernel(const WsArgs a) {
       cur.rs[3] = 0x00020000;
       const int tm0 = lt.tx * a.TTO - f.dil + r0, tm1 = tm0 + HR;  // time of this thread's two rows
       const int sr0 = f.rsz == RESIZE_UP2 ? (tm0 >> 1) : (f.rsz == RESIZE_AVG2 ? 2 * tm0 : tm0);  // (first) source row of row 0
-      cur.off0 = (sr0 * f.Csrc + f.c0 + (f.ntaps == 0 ? lt.ty * CT : 0) + oct * 8) * 2;
-      cur.off1 = cur.off0 + (f.rsz == RESIZE_UP2 ? HR : (f.rsz == RESIZE_AVG2 ? 4 * HR : 2 * HR)) * f.Csrc;
-      cur.db = f.rsz == RESIZE_AVG2 ? 2 * f.Csrc : 0x40000000;
+      cur.off0 = (sr0 * f.Csrc + f.c0 + (f.ntaps == 0 ? lt.ty * CT : 0) + oct * 8) * ES;
+      cur.off1 = cur.off0 + (f.rsz == RESIZE_UP2 ? HR : (f.rsz == RESIZE_AVG2 ? 4 * HR : 2 * HR)) * f.Csrc * (ES / 2);
+      cur.db = X3 ? 16 : (f.rsz == RESIZE_AVG2 ? 2 * f.Csrc : 0x40000000);
       cur_avg = f.rsz == RESIZE_AVG2 ? 1 : 0;
       if (__builtin_expect(lseg == 0 && lt.b != ss_clip, 0)) {
         ss_clip = lt.b;
@@ -382,8 +398,8 @@ __global__ __launch_bounds__(ROWS * 4) void conv_ws_kernel(const WsArgs a) {
           }
           enter();
         } else {
-          cur.off0 += 64;
-          cur.off1 += 64;
+          cur.off0 += 32 * ES;
+          cur.off1 += 32 * ES;
           cur.ssaddr += 256;
         }
       }
@@ -398,7 +414,7 @@ __global__ __launch_bounds__(ROWS * 4) void conv_ws_kernel(const WsArgs a) {
       r.ssaddr = pr.ssaddr;
       if (VQVS_WS_EXP & 1) {
         asm volatile("" : "=v"(r.a0), "=v"(r.a1));  // (opaque garbage, so that nothing downstream folds away)
-        if constexpr (AVG) asm volatile("" : "=v"(r.b0), "=v"(r.b1));
+        if constexpr (L4) asm volatile("" : "=v"(r.b0), "=v"(r.b1));
         return;
       }
       // (the descriptor is wave-uniform by construction; say so, or the compiler may hand the assembly a VGPR copy of it when it
@@ -406,7 +422,7 @@ __global__ __launch_bounds__(ROWS * 4) void conv_ws_kernel(const WsArgs a) {
       i32x4 rs;
 #pragma unroll
       for (int i = 0; i < 4; ++i) rs[i] = __builtin_amdgcn_readfirstlane(pr.rs[i]);
-      if constexpr (AVG) {
+      if constexpr (L4) {
         const int ob0 = pr.off0 + pr.db, ob1 = pr.off1 + pr.db;
         asm volatile(
             "s_nop 4\n\t"
@@ -427,7 +443,7 @@ __global__ __launch_bounds__(ROWS * 4) void conv_ws_kernel(const WsArgs a) {
     };
     auto acquire = [&](Raw& r) {  // the oldest chunk in flight has landed; nothing that reads it may be scheduled above this
       if (VQVS_WS_EXP & 1) return;
-      if constexpr (AVG)
+      if constexpr (L4)
         asm volatile("s_waitcnt vmcnt(8)" : "+v"(r.a0), "+v"(r.a1), "+v"(r.b0), "+v"(r.b1));
       else
         asm volatile("s_waitcnt vmcnt(4)" : "+v"(r.a0), "+v"(r.a1));
@@ -490,6 +506,39 @@ __global__ __launch_bounds__(ROWS * 4) void conv_ws_kernel(const WsArgs a) {
     auto stage = [&](const Raw& r, int slot) {
       char* const sb = smem + slot * ACT_STRIDE;
       const int um = __builtin_amdgcn_readfirstlane((int)r.meta);
+      if constexpr (X3) {
+        // fp32 rows: exact-erf GELU of the affine (common.hpp gelu_f), then the bf16 hi / lo planes of the result
+        const f32x4 fa0 = __builtin_bit_cast(f32x4, r.a0), fb0 = __builtin_bit_cast(f32x4, r.b0);
+        const f32x4 fa1 = __builtin_bit_cast(f32x4, r.a1), fb1 = __builtin_bit_cast(f32x4, r.b1);
+        f32x8 v0 = {fa0[0], fa0[1], fa0[2], fa0[3], fb0[0], fb0[1], fb0[2], fb0[3]};
+        f32x8 v1 = {fa1[0], fa1[1], fa1[2], fa1[3], fb1[0], fb1[1], fb1[2], fb1[3]};
+        if ((um & 1) && !(VQVS_WS_EXP & 8)) {
+          const f32x4* const sp = reinterpret_cast<const f32x4*>(smem + r.ssaddr);
+          const f32x4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
+          const float sc[8] = {s0[0], s0[2], s1[0], s1[2], s2[0], s2[2], s3[0], s3[2]};
+          const float sh[8] = {s0[1], s0[3], s1[1], s1[3], s2[1], s2[3], s3[1], s3[3]};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            v0[e] = gelu_f(fmaf(v0[e], sc[e], sh[e]));
+            v1[e] = gelu_f(fmaf(v1[e], sc[e], sh[e]));
+          }
+        }
+        if (um & 32) {  // (edge tiles: rows outside the clip are the convolution's zero padding)
+          const float m0 = (r.meta & 2u) ? 1.f : 0.f, m1 = (r.meta & 4u) ? 1.f : 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            v0[e] *= m0;
+            v1[e] *= m1;
+          }
+        }
+        bf16x8 h0, l0, h1, l1;
+        split_bf16(v0, h0, l0);
+        split_bf16(v1, h1, l1);
+        *reinterpret_cast<bf16x8*>(sb + dst0) = h0;
+        *reinterpret_cast<bf16x8*>(sb + ACT_BYTES + dst0) = l0;
+        *reinterpret_cast<bf16x8*>(sb + dst0 + HR * 64) = h1;
+        *reinterpret_cast<bf16x8*>(sb + ACT_BYTES + dst0 + HR * 64) = l1;
+      } else {
       u32x4 o0 = r.a0, o1 = r.a1;
       if ((um & 1) && !(VQVS_WS_EXP & 8)) {
         const f32x4* const sp = reinterpret_cast<const f32x4*>(smem + ((VQVS_WS_EXP & 64) ? 0 : r.ssaddr));
@@ -522,6 +571,7 @@ __global__ __launch_bounds__(ROWS * 4) void conv_ws_kernel(const WsArgs a) {
       }
       *reinterpret_cast<u32x4*>(sb + dst0) = o0;
       *reinterpret_cast<u32x4*>(sb + dst0 + HR * 64) = o1;
+      }
     };
 
     {
@@ -568,6 +618,7 @@ __global__ __launch_bounds__(ROWS * 4) void conv_ws_kernel(const WsArgs a) {
     const int wt = wave % NWT, wc = wave / NWT;  // time slice (RW rows), channel half (WN x 32 channels)
     const int l31 = lane & 31, hh = lane >> 5;
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_wl = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(X3 ? a.w_lo : a.w), 0, a.w_bytes, 0x00020000);
     T* const outp = reinterpret_cast<T*>(a.out);
 
     f32x16 acc[MT][WN];
@@ -644,6 +695,7 @@ __global__ __launch_bounds__(ROWS * 4) void conv_ws_kernel(const WsArgs a) {
         const int tap = (p * 16) / CT, colb = p * 16 - tap * CT;
         const int voff = wb + (tap * a.Cout + colb) * 64 + dma_lane;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(smem + WS_OFF + slot * WS_STRIDE + p * 1024), 16, voff, 0, 0, 0);
+        if constexpr (X3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wl, (lds_ptr)(smem + WS_OFF + slot * WS_STRIDE + W_BYTES + p * 1024), 16, voff, 0, 0, 0);
       }
     };
     auto sync_all = [&]() {  // + this wave's weight DMA has landed (streaming form; with resident weights nothing waits for VMEM:
@@ -679,7 +731,7 @@ __global__ __launch_bounds__(ROWS * 4) void conv_ws_kernel(const WsArgs a) {
         float2* o = reinterpret_cast<float2*>(a.stats) + ((size_t)pt_.b * a.ntiles_stat + pt_.tx) * a.Cout + co0 + ltid;
         *o = float2{t1, t2};
       }
-      if constexpr (WPE) return;  // (the rows left with their wave, at the tile's last step)
+      if constexpr (WPE || X3) return;  // (the rows left with their wave, at the tile's last step)
       // out-tile -> global: a thread takes 8 channels of a row pair (2 x 16 B of LDS), separates the two rows (lo / hi halves of
       // the dwords) and stores 16 B of each; a wave writes whole 2 x CT-byte rows
       constexpr int PPR = CT / 8;  // 8-channel pieces per row
@@ -732,8 +784,11 @@ __global__ __launch_bounds__(ROWS * 4) void conv_ws_kernel(const WsArgs a) {
       for (int sg = 0; sg < nsg; ++sg) {
         const int np = (WS_SEGF(sg, nch) * WS_SEGF(sg, wstep)) >> 10;
         const int gb = WS_SEGF(sg, wbase), lb = WS_SEGF(sg, lds_off);
-        for (int p = wave; p < np; p += NCW)
+        for (int p = wave; p < np; p += NCW) {
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(smem + WRES_OFF + lb + p * 1024), 16, gb + p * 1024 + dma_lane, 0, 0, 0);
+          if constexpr (X3)  // (the lo plane sits behind all hi images)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wl, (lds_ptr)(smem + WRES_OFF + a.wres_bytes + lb + p * 1024), 16, gb + p * 1024 + dma_lane, 0, 0, 0);
+        }
       }
     }
     auto dma_advance = [&]() {
@@ -826,7 +881,23 @@ __global__ __launch_bounds__(ROWS * 4) void conv_ws_kernel(const WsArgs a) {
 #pragma unroll
             for (int nt = 0; nt < WN; ++nt) {
               const V8 bf = *reinterpret_cast<const V8*>(smem + (NKS == 2 ? bad[nt][ks % NKS] : (bad[nt][0] ^ (ks * 32))) + k * (CT * 64));
-              if (VQVS_WS_EXP & 4096) {  // ablation: the fragment reads stay, the MFMAs go
+              if constexpr (X3) {
+                // hi * hi + lo * hi + hi * lo (activation lo plane ACT_BYTES behind the hi plane, weight lo plane W_BYTES / all hi
+                // images behind)
+                const V8 bl = *reinterpret_cast<const V8*>(smem + bad[nt][ks % NKS] + k * (CT * 64) + (RES ? a.wres_bytes : W_BYTES));
+                const V8 a0l = *reinterpret_cast<const V8*>(sb + ACT_BYTES + ao);
+                const V8 a1l = *reinterpret_cast<const V8*>(sb + ACT_BYTES + ao + 32 * 64);
+                acc[0][nt] = ws_mfma(a0, bf, acc[0][nt]);
+                acc[MT - 1][nt] = ws_mfma(a1, bf, acc[MT - 1][nt]);
+                if (!(VQVS_WS_EXP & 8192)) {
+                acc[0][nt] = ws_mfma(a0l, bf, acc[0][nt]);
+                acc[MT - 1][nt] = ws_mfma(a1l, bf, acc[MT - 1][nt]);
+                }
+                if (!(VQVS_WS_EXP & 16384)) {
+                acc[0][nt] = ws_mfma(a0, bl, acc[0][nt]);
+                acc[MT - 1][nt] = ws_mfma(a1, bl, acc[MT - 1][nt]);
+                }
+              } else if (VQVS_WS_EXP & 4096) {  // ablation: the fragment reads stay, the MFMAs go
                 asm volatile("" ::"v"(a0), "v"(a1), "v"(bf));
               } else {
                 acc[0][nt] = ws_mfma(a0, bf, acc[0][nt]);
@@ -869,7 +940,46 @@ __global__ __launch_bounds__(ROWS * 4) void conv_ws_kernel(const WsArgs a) {
               for (int r = 0; r < 16; ++r)
                 if (mt * 32 + (r & 3) + 8 * (r >> 2) >= lim) acc[mt][nt][r] = 0.f;
         }
-        if constexpr (WPE) {
+        if constexpr (X3) {
+          // fp32 storage: the identity skip (unet.py:316) is added HERE, exactly, from global memory in the accumulators' own
+          // layout (a lane = one output channel, 32 lanes = 128 contiguous bytes of a row); statistics of the stored values; rows
+          // leave as dwords through a descriptor that ends behind the tile's last valid row.
+          const int ch = ct.ty * CT + wc * (WN * 32) + l31 + zl;
+          float* const outf = reinterpret_cast<float*>(a.out);
+          const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(
+              outf + (size_t)ct.b * a.Lout * a.Cout, 0, (t0 + nvalid) * a.Cout * 4, 0x00020000);
+          const int row0 = t0 + wt * RW + 4 * hh;  // this lane's first row (of the clip); + mt * 32 + (r & 3) + 8 * (r >> 2)
+          if (a.skip != nullptr) {
+            const float* const sk = reinterpret_cast<const float*>(a.skip) + (size_t)ct.b * a.skip_L * a.Cout + ch;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const int row = row0 + mt * 32 + (r & 3) + 8 * (r >> 2);
+                float x = 0.f;
+                if (row < t0 + nvalid) {
+                  if (a.skip_rsz == RESIZE_UP2) x = sk[(size_t)(row >> 1) * a.Cout];
+                  else if (a.skip_rsz == RESIZE_AVG2) x = (sk[(size_t)(2 * row) * a.Cout] + sk[(size_t)(2 * row + 1) * a.Cout]) * 0.5f;
+                  else x = sk[(size_t)row * a.Cout];
+                }
+                acc[mt][0][r] += x;
+              }
+          }
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float v = acc[mt][0][r];  // (rows past the tile's end were zeroed above)
+              s1 += v;
+              s2 = fmaf(v, v, s2);
+              if (!(VQVS_WS_EXP & 4))
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_o, ((row0 + mt * 32 + (r & 3) + 8 * (r >> 2)) * a.Cout + ch) * 4, 0, 0);
+            }
+          s1 += __shfl_xor(s1, 32);
+          s2 += __shfl_xor(s2, 32);
+          if (hh == 0) reinterpret_cast<float2*>(smem + R_OFF)[wt * CT + wc * (WN * 32) + l31 + zl] = float2{s1, s2};
+        } else if constexpr (WPE) {
           // Wave-private epilogue: 16 rows at a time (accumulator registers 4 j .. 4 j + 3 of both row blocks) are rounded in PAIRS
           // of rows into this wave's 2 KiB region ([8 row pairs][64 channels] dwords), read back as 8-channel pieces of a pair,
           // un-zipped (v_perm) and stored: a lane writes 16 B of each of two rows, 8 lanes one 128-byte row segment.  LDS
@@ -1039,10 +1149,10 @@ int ws_num_cus() {
 }
 
 // LDS bytes besides resident weights and the (scale, shift) ring (the kernel's layout constants, restated for the planner)
-constexpr int ws_fixed_lds(int rows, int ct, bool res) {
-  const int ncw = rows / 32, nwt = ct == 32 ? rows / 32 : rows / 64, db = ct == 32 ? 2 : 1;
-  const int obytes = (res && ct == 128) ? ncw * 2048 : (rows / 2) * (ct * 4 + 16);
-  return (res ? 2 * rows * 64 : 2 * (rows * 64 + 3 * ct * 64)) + db * obytes + db * nwt * ct * 8 + (res ? 4096 : 0);
+constexpr int ws_fixed_lds(int rows, int ct, bool res, bool x3 = false) {
+  const int ncw = rows / 32, nwt = ct == 32 ? rows / 32 : rows / 64, db = ct == 32 ? 2 : 1, pl = x3 ? 2 : 1;
+  const int obytes = x3 ? 0 : ((res && ct == 128) ? ncw * 2048 : (rows / 2) * (ct * 4 + 16));
+  return (res ? 2 * pl * rows * 64 : 2 * pl * (rows * 64 + 3 * ct * 64)) + db * obytes + db * nwt * ct * 8 + (res ? 4096 : 0);
 }
 constexpr int WS_LDS_MAX = 160 * 1024;
 // LDS one workgroup may use: two workgroups of the 128-row geometry share a CU
@@ -1050,7 +1160,8 @@ constexpr int ws_lds_cap(int rows) { return rows == 256 ? WS_LDS_MAX : WS_LDS_MA
 
 template <typename T, int ROWS, int CT, bool RES, bool AVG>
 int ws_launch(const WsArgs& w, hipStream_t st) {
-  const int lds = ws_fixed_lds(ROWS, CT, RES) + (RES ? w.wres_bytes : 0) + w.ss_ring * w.ss_bytes;
+  constexpr bool X3 = sizeof(T) == 4;
+  const int lds = ws_fixed_lds(ROWS, CT, RES, X3) + (RES ? (X3 ? 2 : 1) * w.wres_bytes : 0) + w.ss_ring * w.ss_bytes;
   static std::atomic<bool> attr_done[WS_MAX_DEV];  // (per instantiation and device; setting it twice from two threads is harmless)
   const int dev = ws_cur_dev();
   if (!attr_done[dev].load(std::memory_order_acquire)) {
@@ -1071,6 +1182,9 @@ int ws_launch_f(const WsArgs& w, bool res, bool avg, hipStream_t st) {
   if (avg && res) return -1;
   if (avg) return ws_launch<T, ROWS, CT, false, true>(w, st);
   return res ? ws_launch<T, ROWS, CT, true, false>(w, st) : ws_launch<T, ROWS, CT, false, false>(w, st);
+}
+int ws_launch_f32(const WsArgs& w, bool res, hipStream_t st) {  // fp32 storage: 256 x 64 tiles, no avg-pooled segments
+  return res ? ws_launch<float, 256, 64, true, false>(w, st) : ws_launch<float, 256, 64, false, false>(w, st);
 }
 template <typename T>
 int ws_launch_t(const WsArgs& w, int rows, int CT, bool res, bool avg, hipStream_t st) {
@@ -1119,33 +1233,40 @@ int launch_conv_ws(const ConvArgs& a, int B, int precision, hipStream_t st) {
   WsPlan plan;
   if (!ws_plan(a, B, precision, plan)) return 0;
   if (a.gn != nullptr && !plan.gn) return 0;  // (the caller launches gn_prepare and comes back without a.gn)
-  const int rc = precision == 2 ? ws_launch_t<half_t>(plan.w, plan.rows, plan.CT, plan.res, plan.avg, st)
-                                : ws_launch_t<bf16_t>(plan.w, plan.rows, plan.CT, plan.res, plan.avg, st);
+  const int rc = precision == 0 ? ws_launch_f32(plan.w, plan.res, st)
+                 : precision == 2 ? ws_launch_t<half_t>(plan.w, plan.rows, plan.CT, plan.res, plan.avg, st)
+                                  : ws_launch_t<bf16_t>(plan.w, plan.rows, plan.CT, plan.res, plan.avg, st);
   return rc < 0 ? rc : 1;
 }
 
 namespace {
 bool ws_plan(const ConvArgs& a, int B, int precision, WsPlan& plan) {
-  if (!ws_enabled() || precision == 0) return 0;
+  const bool x3 = precision == 0;  // fp32 storage: only where the caller allows it (ConvArgs.ws_f32) and the lo weights exist
+  static const int f32_env = getenv("VQVS_WS_F32") ? atoi(getenv("VQVS_WS_F32")) : 1;  // 0: the fp32 mode stays on conv_mfma_kernel (A/B)
+  if (!ws_enabled() || (x3 && (!a.ws_f32 || !f32_env || a.w_lo == nullptr || a.Cout % 64 != 0))) return 0;
+  const int es = x3 ? 4 : 2;
+  if (x3 && f32_env == 2 && a.skip != nullptr) return 0;  // (debug: only launches without / with an identity skip)
+  if (x3 && f32_env == 3 && a.skip == nullptr) return 0;
+  if (x3 && f32_env == 4 && a.seg[0].ss != nullptr) return 0;
   if (a.Cout % 32 != 0 || a.out_f32 || a.epi_gelu || a.nbw || (a.out_rows != 0 && a.out_rows != a.Lout)) return 0;
   // rows per clip a source must have for a given resize (kernels.hpp RESIZE_*)
   auto len_ok = [&](int rsz, int Lsrc) { return rsz == RESIZE_UP2 ? Lsrc * 2 == a.Lout : (rsz == RESIZE_AVG2 ? Lsrc / 2 == a.Lout : Lsrc == a.Lout); };
-  if (a.skip != nullptr && (a.skip_C != a.Cout || !len_ok(a.skip_resize, a.skip_L) || (long long)a.skip_L * a.skip_C * 2 >= (1LL << 29))) return 0;
+  if (a.skip != nullptr && (a.skip_C != a.Cout || !len_ok(a.skip_resize, a.skip_L) || (long long)a.skip_L * a.skip_C * es >= (1LL << 29))) return 0;
   bool avg = a.skip != nullptr && a.skip_resize == RESIZE_AVG2;
-  const int CT = a.Cout % 128 == 0 ? 128 : (a.Cout % 64 == 0 ? 64 : 32);
+  const int CT = x3 ? 64 : (a.Cout % 128 == 0 ? 128 : (a.Cout % 64 == 0 ? 64 : 32));
   plan.w = WsArgs{};
   WsArgs& w = plan.w;
   int dmax = 0, n = 0;
   for (int s = 0; s < a.nseg; ++s) {
     const SegDesc& g = a.seg[s];
     if (g.C % 32 != 0 || (g.ntaps != 1 && g.ntaps != 3) || !len_ok(g.resize, g.Lsrc)) return 0;
-    if ((long long)g.Lsrc * g.Csrc * 2 >= (1LL << 29)) return 0;  // (the dummy loads of an AVG launch rely on offset + 2^30 being out of range)
+    if ((long long)g.Lsrc * g.Csrc * es >= (1LL << 29)) return 0;  // (the dummy loads of an AVG launch rely on offset + 2^30 being out of range)
     avg = avg || g.resize == RESIZE_AVG2;
     WsSeg& q = w.seg[s];
     q.src = g.src;
     q.ss = g.ss;
     q.Csrc = g.Csrc;
-    q.clip_bytes = g.Lsrc * g.Csrc * 2;
+    q.clip_bytes = g.Lsrc * g.Csrc * es;
     q.c0 = g.c0;
     q.nch = g.C / 32;
     q.ntaps = g.ntaps;
@@ -1163,7 +1284,11 @@ bool ws_plan(const ConvArgs& a, int B, int precision, WsPlan& plan) {
     n += q.nch;
   }
   w.nseg = a.nseg;
-  if (a.skip != nullptr) {
+  if (a.skip != nullptr && x3) {  // (fp32 storage adds the skip in the epilogue, exactly)
+    w.skip = a.skip;
+    w.skip_L = a.skip_L;
+    w.skip_rsz = a.skip_resize;
+  } else if (a.skip != nullptr) {
     WsSeg& q = w.seg[w.nseg++];
     q.src = a.skip;
     q.ss = nullptr;
@@ -1177,11 +1302,13 @@ bool ws_plan(const ConvArgs& a, int B, int precision, WsPlan& plan) {
     n += q.nch;
   }
   // the staged window: 256 rows, or 128 (tile_rows = 128 - 2 dmax, chosen by the schedule builder: conv_tile_rows)
+  if (x3 && (avg || a.tile_rows != 256 - 2 * dmax)) return 0;
   const int rows = a.tile_rows == 256 - 2 * dmax ? 256 : (a.tile_rows == 128 - 2 * dmax && CT >= 64 && a.tile_rows > 0 ? 128 : 0);
   if (rows == 0 || a.w_bytes > 0x7fffffffLL || n < (CT == 32 ? 1 : 2)) return 0;
   plan.rows = rows;
   w.nchunks = n;
   w.w = a.w_hi;
+  w.w_lo = a.w_lo;
   w.w_bytes = (int)a.w_bytes;
   w.bias = a.bias;
   w.out = a.out;
@@ -1201,13 +1328,13 @@ bool ws_plan(const ConvArgs& a, int B, int precision, WsPlan& plan) {
   if (w.ss_bytes > 8192) return 0;  // (one 16-byte piece per producer thread)
   w.ss_ring = (long long)w.ntx * w.nty * n >= 4 ? 2 : 4;
   const int ss_total = w.ss_ring * w.ss_bytes;
-  if (ws_fixed_lds(rows, CT, false) + ss_total > ws_lds_cap(rows)) return 0;
+  if (ws_fixed_lds(rows, CT, false, x3) + ss_total > ws_lds_cap(rows)) return 0;
   // (avg-pooled launches stream their weights: resident weights + four loads per chunk do not fit 128 VGPRs without spills, and
   //  compiler-generated scratch traffic has no place beside the producers' counted waits)
   if (w.ntiles >= (1 << 24)) return 0;  // (the kernel's tile-range arithmetic is 32-bit)
   plan.CT = CT;
   plan.avg = avg;
-  plan.res = res_env && !avg && w.nty == 1 && ws_fixed_lds(rows, CT, true) + w.wres_bytes + ss_total <= ws_lds_cap(rows);
+  plan.res = res_env && !avg && w.nty == 1 && ws_fixed_lds(rows, CT, true, x3) + (x3 ? 2 : 1) * w.wres_bytes + ss_total <= ws_lds_cap(rows);
   if (plan.res && CT == 128 && (long long)a.Lout * CT * 2 >= (1LL << 31)) return 0;  // (the wave-private epilogue's store descriptor covers one clip)
   // GroupNorm built by the producers (WsGn): every prologue segment is one whole source of *a.gn, in order; a group is a power of
   // two of lanes; few enough tile partials per channel that the serial sum at a clip change stays short

@@ -81,6 +81,8 @@ struct ConvArgs {
   // from seg[].ss but built by the convolution's producers from the tile partials described here (every prologue segment is one
   // source of *gn, in order, whole).  Only launch_conv_ws honours it, and only where ws_fuses_gn() says so.
   const GnArgs* gn;
+  int ws_f32;  // VQVS_PREC_F32 only: 1 = the launch may run on conv_ws_kernel's fp32 form (never set for the encoders, whose output is
+               // vector-quantised: their convolutions keep one summation order, conv_mfma_kernel's, so codes stay bit-stable)
   int rev;  // 1: walk the tiles from the last clip to the first (consecutive launches alternate: a launch starts on what its
             // predecessor wrote last, which is what the Infinity Cache still holds); results do not depend on it
 };

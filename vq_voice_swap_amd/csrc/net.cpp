@@ -416,7 +416,9 @@ class Builder {
     int dmax = 0;
     for (auto& g : segs)
       if (g.ntaps == 3 && g.dil > dmax) dmax = g.dil;
-    const bool ws_ok = !out.f32 && !epi_gelu && fuse == nullptr && out_lshift == -1000;
+    int kchunks = skip ? 2 : 0;  // (K chunks of 32 channels per tile: a one-chunk tile is only covered at 32 output channels)
+    for (auto& g : segs) kchunks += g.C / 32;
+    const bool ws_ok = !out.f32 && !epi_gelu && fuse == nullptr && out_lshift == -1000 && kchunks >= 2;
     const int tile_rows = conv_tile_rows(dmax, Cout, m_->cfg.precision, ws_ok);
     if (out.has_stats) tile_rows_[out.id] = tile_rows;
     // cost
@@ -437,6 +439,7 @@ class Builder {
     for (auto& s : segs) desc += (desc.empty() ? "" : "+") + std::to_string(s.C) + "x" + std::to_string(s.ntaps) + (s.resize == RESIZE_AVG2 ? "v" : s.resize == RESIZE_UP2 ? "^" : "") + (s.ntaps == 3 && s.dil > 1 ? "d" + std::to_string(s.dil) : "");
     desc += "->" + std::to_string(Cout) + " L>>" + std::to_string(out.lshift) + (skip ? " +id" : "");
     m_->meta.push_back({"conv", desc, conv_elems, conv_f32, conv_flops});
+    const int ws_f32 = (m_->cfg.kind == VQVS_KIND_PREDICTOR || m_->cfg.kind == VQVS_KIND_RESBLOCK) ? 1 : 0;
     const int rev = (conv_seq_++) & 1;  // consecutive convolutions walk their tiles in opposite directions (ConvArgs.rev)
     auto build = [=](const RunCtx& c, ConvArgs& a) {
       a.nseg = (int)S.size();
@@ -475,6 +478,7 @@ class Builder {
       a.ntiles = ntiles_of(a.Lout, tile_rows);
       a.tile_rows = tile_rows;
       a.rev = rev;
+      a.ws_f32 = ws_f32;
       if (has_fuse) {
         a.nbw = (int)F.xf.size();
         int c0 = 0;
