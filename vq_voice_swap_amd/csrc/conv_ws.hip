@@ -853,6 +853,35 @@ __global__ __launch_bounds__(ROWS * 4) void conv_ws_kernel(const WsArgs a) {
       }
       WS_TMARK(1)
       const char* const sb = smem + (g & 1) * ACT_STRIDE;
+      // fp32 storage: the identity-skip rows of this tile (accumulator layout) are requested before the tile's LAST chunk is
+      // multiplied, so that their latency passes behind its MFMAs instead of in front of the epilogue
+      float skv[MT][16];
+      if constexpr (X3) {
+        if (cci == n - 1 && a.skip != nullptr) {
+          // (buffer loads through a descriptor that ends behind the tile's last valid row of the SOURCE: rows past it read as zero)
+          const int t0 = ct.tx * a.TTO;
+          const int lastrow = t0 + min(a.TTO, a.Lout - t0);
+          const int srows = a.skip_rsz == RESIZE_UP2 ? (lastrow + 1) >> 1 : (a.skip_rsz == RESIZE_AVG2 ? 2 * lastrow : lastrow);
+          const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(
+              const_cast<float*>(reinterpret_cast<const float*>(a.skip)) + (size_t)ct.b * a.skip_L * a.Cout, 0, srows * a.Cout * 4, 0x00020000);
+          const int row0 = t0 + wt * RW + 4 * hh;
+          const int ch4 = (ct.ty * CT + wc * (WN * 32) + l31) * 4;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = row0 + mt * 32 + (r & 3) + 8 * (r >> 2);
+              if (a.skip_rsz == RESIZE_AVG2) {
+                const float x0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_s, (2 * row) * a.Cout * 4 + ch4, 0, 0));
+                const float x1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_s, (2 * row + 1) * a.Cout * 4 + ch4, 0, 0));
+                skv[mt][r] = (x0 + x1) * 0.5f;
+              } else {
+                const int sr = a.skip_rsz == RESIZE_UP2 ? (row >> 1) : row;
+                skv[mt][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_s, sr * a.Cout * 4 + ch4, 0, 0));
+              }
+            }
+        }
+      }
       {
         if (d != aoff_d) {  // A-fragment offsets of the three taps (swizzled rows: not additive in the tap), rebuilt when the dilation changes
           aoff_d = d;
@@ -950,20 +979,10 @@ __global__ __launch_bounds__(ROWS * 4) void conv_ws_kernel(const WsArgs a) {
               outf + (size_t)ct.b * a.Lout * a.Cout, 0, (t0 + nvalid) * a.Cout * 4, 0x00020000);
           const int row0 = t0 + wt * RW + 4 * hh;  // this lane's first row (of the clip); + mt * 32 + (r & 3) + 8 * (r >> 2)
           if (a.skip != nullptr) {
-            const float* const sk = reinterpret_cast<const float*>(a.skip) + (size_t)ct.b * a.skip_L * a.Cout + ch;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                const int row = row0 + mt * 32 + (r & 3) + 8 * (r >> 2);
-                float x = 0.f;
-                if (row < t0 + nvalid) {
-                  if (a.skip_rsz == RESIZE_UP2) x = sk[(size_t)(row >> 1) * a.Cout];
-                  else if (a.skip_rsz == RESIZE_AVG2) x = (sk[(size_t)(2 * row) * a.Cout] + sk[(size_t)(2 * row + 1) * a.Cout]) * 0.5f;
-                  else x = sk[(size_t)row * a.Cout];
-                }
-                acc[mt][0][r] += x;
-              }
+              for (int r = 0; r < 16; ++r) acc[mt][0][r] += skv[mt][r];
           }
           float s1 = 0.f, s2 = 0.f;
 #pragma unroll
