@@ -143,6 +143,7 @@ struct WsGn {
   const float *part0, *part1;  // [B][ntiles][C][2] of the (one or two) sources
   int ntiles0, ntiles1, C0, C1;
   int nsrc, Ctot, cpg, nclips;
+  int tpc;  // lanes per channel (1, 2, 4 or 8): the tile partials of a channel are summed in `tpc` interleaved slices
   double inv_count;
   const float *gamma, *beta, *film;
   int film_stride, film_off;
@@ -645,40 +646,61 @@ __global__ __launch_bounds__(ROWS * 4) void conv_ws_kernel(const WsArgs a) {
     };
     if constexpr (RES) write_consts(C_OFF);
     auto gn_table = [&](int b) {
-      if (b < 0 || b >= a.gn.nclips) return;
+      // (the descriptor is read through an opaque pointer: its scalar loads then stay inside this rare block instead of being
+      //  hoisted out of the K loop, where they cost the kernel its last SGPRs)
+      typedef const __attribute__((address_space(4))) WsGn* GnPtr;  // (WsArgs is the kernel's only parameter, WsGn its first member)
+      GnPtr G = (GnPtr)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(G));
+      if (b < 0 || b >= G->nclips) return;
       char* const tab = smem + SS_OFF + (b & (a.ss_ring - 1)) * a.ss_bytes;
-      for (int c = tid; c < a.gn.Ctot; c += NPT) {  // (Ctot and C0 are multiples of 64: a wave stays whole and inside one source)
-        const bool second = c >= a.gn.C0;
-        const int cl = second ? c - a.gn.C0 : c;
-        const int nt = second ? a.gn.ntiles1 : a.gn.ntiles0, Cs = second ? a.gn.C1 : a.gn.C0;
-        const float* p = (second ? a.gn.part1 : a.gn.part0) + ((size_t)(unsigned)b * (unsigned)nt * (unsigned)Cs + (unsigned)cl) * 2;
+      // a wave takes 64 / tpc channels, a lane one slice (tiles j, j + tpc, ...) of one channel; eight loads in flight per lane
+      const int tpc = G->tpc, chw = 64 / tpc;
+      const int cl = lane & (chw - 1), j = lane / chw;
+      for (int cb = wave * chw; cb < G->Ctot; cb += NCW * chw) {  // (C0 is a multiple of 64: a wave stays inside one source)
+        const int c = cb + cl;
+        const bool second = c >= G->C0;
+        const int ccl = second ? c - G->C0 : c;
+        const int nt = second ? G->ntiles1 : G->ntiles0, Cs = second ? G->C1 : G->C0;
+        const float* p = (second ? G->part1 : G->part0) + ((size_t)(unsigned)b * (unsigned)nt * (unsigned)Cs + (unsigned)ccl) * 2;
         double s1 = 0.0, s2 = 0.0;
         unsigned bad = 0;
-        for (int t = 0; t < nt; ++t) {
-          const float2 q = *reinterpret_cast<const float2*>(p + (size_t)t * Cs * 2);
-          s1 += (double)q.x;
-          s2 += (double)q.y;
-          if (!(fabsf(q.x) <= 3.0e38f) || !(q.y <= 3.0e38f)) bad |= 1u;  // (the range guard of gn_prepare_kernel)
-          if (a.gn.guard && q.y >= 9.0e8f) bad |= 2u;
+        for (int t0 = j; t0 < nt; t0 += 8 * tpc) {
+          float2 q[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int t = t0 + k * tpc;
+            q[k] = t < nt ? *reinterpret_cast<const float2*>(p + (size_t)t * Cs * 2) : float2{0.f, 0.f};
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            s1 += (double)q[k].x;
+            s2 += (double)q[k].y;
+            if (!(fabsf(q[k].x) <= 3.0e38f) || !(q[k].y <= 3.0e38f)) bad |= 1u;  // (the range guard of gn_prepare_kernel)
+            if (G->guard && q[k].y >= 9.0e8f) bad |= 2u;
+          }
         }
-        if (bad && a.gn.status) atomicOr(a.gn.status, bad);
-        for (int off = 1; off < a.gn.cpg; off <<= 1) {
+        if (bad && G->status) atomicOr(G->status, bad);
+        for (int off = chw; off < 64; off <<= 1) {  // the slices of a channel ...
           s1 += __shfl_xor(s1, off);
           s2 += __shfl_xor(s2, off);
         }
-        const double mean = s1 * a.gn.inv_count;
-        double var = s2 * a.gn.inv_count - mean * mean;
+        for (int off = 1; off < G->cpg; off <<= 1) {  // ... then the channels of a group (cpg <= chw)
+          s1 += __shfl_xor(s1, off);
+          s2 += __shfl_xor(s2, off);
+        }
+        const double mean = s1 * G->inv_count;
+        double var = s2 * G->inv_count - mean * mean;
         if (var < 0.0) var = 0.0;
         const double rstd = 1.0 / sqrt(var + 1e-5);
-        double scale = rstd * (double)a.gn.gamma[c];
-        double shift = (double)a.gn.beta[c] - mean * scale;
-        if (a.gn.film) {
-          const float* f = a.gn.film + (size_t)(unsigned)b * a.gn.film_stride + a.gn.film_off;
+        double scale = rstd * (double)G->gamma[c];
+        double shift = (double)G->beta[c] - mean * scale;
+        if (G->film) {
+          const float* f = G->film + (size_t)(unsigned)b * G->film_stride + G->film_off;
           const double fa = (double)f[c] + 1.0;
           scale *= fa;
-          shift = shift * fa + (double)f[a.gn.Ctot + c];
+          shift = shift * fa + (double)f[G->Ctot + c];
         }
-        *reinterpret_cast<float2*>(tab + c * 8) = float2{(float)scale, (float)shift};
+        if (j == 0) *reinterpret_cast<float2*>(tab + c * 8) = float2{(float)scale, (float)shift};
       }
     };
     const int gn_ahead = a.gn.nsrc > 0 ? (a.ss_ring >> 1) * (a.rev ? -1 : 1) : 0;  // clips between a table's construction and its clip
@@ -1359,6 +1381,8 @@ bool ws_plan(const ConvArgs& a, int B, int precision, WsPlan& plan) {
   // two of lanes; few enough tile partials per channel that the serial sum at a clip change stays short
   plan.gn = false;
   static const int gn_env = getenv("VQVS_WS_GN") ? atoi(getenv("VQVS_WS_GN")) : 1;  // 0: always the gn_prepare launch (A/B measurements)
+  // (clips of up to 8 tiles: measured +0.6 % clips/s; from 16 tiles on the table's construction costs what its gn_prepare launch
+  //  did -- 66.19 / 66.08 / 66.01 clips/s at 16 / 32 / 64 against 66.16 at 8, 67.1 against 67.5 with every launch fused)
   static const int gn_max_tiles = getenv("VQVS_WS_GN_TILES") ? atoi(getenv("VQVS_WS_GN_TILES")) : 8;
   if (a.gn != nullptr && gn_env) {
     const GnArgs& g = *a.gn;
@@ -1384,6 +1408,13 @@ bool ws_plan(const ConvArgs& a, int B, int precision, WsPlan& plan) {
       G.nclips = B;
       G.Ctot = g.Ctot;
       G.cpg = cpg;
+      {  // slices per channel: enough that a lane adds at most ~32 partials, as long as a group still fits the wave's channels
+        int mt = 0;
+        for (int i = 0; i < g.nsrc; ++i) mt = g.src[i].ntiles > mt ? g.src[i].ntiles : mt;
+        int tpc = 1;
+        while (tpc < 8 && mt > 8 * tpc && cpg * 2 * tpc <= 64) tpc *= 2;
+        G.tpc = tpc;
+      }
       G.inv_count = g.inv_count;
       G.gamma = g.gamma;
       G.beta = g.beta;
