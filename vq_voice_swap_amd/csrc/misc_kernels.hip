@@ -1,6 +1,8 @@
 // Bandwidth-bound and tiny kernels around the MFMA convolutions: the 1->C input conv, the
 // C->1 output conv, GroupNorm/FiLM coefficient preparation, the timestep embedding, and the
 // NCT<->NTC layout changes at the library boundary.
+#include <atomic>
+
 #include "kernels.hpp"
 
 namespace vqvs {
@@ -296,46 +298,59 @@ __global__ void gelu_rows_kernel(const float* in, float* out, int n) {
   if (i < n) out[i] = gelu_f(in[i]);
 }
 
-// film[b][r] = bias[r] + W[r] . gemb[b].  W is stored TRANSPOSED ([E][R]): thread = one output row r (coalesced
-// weight reads), 32 clips accumulated in registers per pass, gemb staged in LDS as [e][32 clips].
+// film[b][r] = bias[r] + W[r] . gemb[b].  W is stored TRANSPOSED ([E][R]): a workgroup owns 64 output rows r (lane = row: coalesced
+// weight reads) of 32 clips; its four waves split E, each accumulating 32 clips in registers against gemb staged in LDS as
+// [e][32 clips], and the four partial sums are added in wave order through LDS (deterministic).  Grid: (R / 64, B / 32).
 constexpr int FILM_NB = 32;
-__global__ __launch_bounds__(128) void film_kernel(const FilmArgs a, int B) {
-  __shared__ __attribute__((aligned(16))) float g[1024 * FILM_NB];
-  const int r = blockIdx.x * 128 + threadIdx.x;
-  const int E = a.E;
-  for (int b0 = 0; b0 < B; b0 += FILM_NB) {
-    const int nb = min(FILM_NB, B - b0);
-    __syncthreads();
-    for (int i = threadIdx.x; i < E * FILM_NB; i += 128) {
-      const int e = i / FILM_NB, bb = i % FILM_NB;
-      g[i] = bb < nb ? a.gemb[(size_t)(b0 + bb) * E + e] : 0.f;
-    }
-    __syncthreads();
-    if (r < a.R) {
-      float acc[FILM_NB];
+__global__ __launch_bounds__(256) void film_kernel(const FilmArgs a, int B) {
+  extern __shared__ __attribute__((aligned(16))) float fsm[];
+  float* const g = fsm;                   // [E][FILM_NB]
+  float* const red = fsm + a.E * FILM_NB;  // [3][64][FILM_NB + 1]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int r = blockIdx.x * 64 + lane;
+  const int E = a.E, b0 = blockIdx.y * FILM_NB;
+  const int nb = min(FILM_NB, B - b0);
+  for (int i = threadIdx.x; i < E * FILM_NB; i += 256) {
+    const int e = i / FILM_NB, bb = i % FILM_NB;
+    g[i] = bb < nb ? a.gemb[(size_t)(b0 + bb) * E + e] : 0.f;
+  }
+  __syncthreads();
+  float acc[FILM_NB];
 #pragma unroll
-      for (int k = 0; k < FILM_NB; ++k) acc[k] = 0.f;
-      for (int e0 = 0; e0 < E; e0 += 8) {
-        float w[8];
+  for (int k = 0; k < FILM_NB; ++k) acc[k] = 0.f;
+  const int eq = E / 4;  // (host: E is a multiple of 32)
+  if (r < a.R) {
+    for (int e0 = wv * eq; e0 < (wv + 1) * eq; e0 += 8) {
+      float w[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) w[u] = a.w[(size_t)(e0 + u) * a.R + r];  // 8 independent loads in flight
+      for (int u = 0; u < 8; ++u) w[u] = a.w[(size_t)(e0 + u) * a.R + r];  // 8 independent loads in flight
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const f32x4* gp = reinterpret_cast<const f32x4*>(&g[(e0 + u) * FILM_NB]);
+      for (int u = 0; u < 8; ++u) {
+        const f32x4* gp = reinterpret_cast<const f32x4*>(&g[(e0 + u) * FILM_NB]);
 #pragma unroll
-          for (int q = 0; q < FILM_NB / 4; ++q) {
-            const f32x4 gv = gp[q];
-            acc[4 * q + 0] = fmaf(w[u], gv[0], acc[4 * q + 0]);
-            acc[4 * q + 1] = fmaf(w[u], gv[1], acc[4 * q + 1]);
-            acc[4 * q + 2] = fmaf(w[u], gv[2], acc[4 * q + 2]);
-            acc[4 * q + 3] = fmaf(w[u], gv[3], acc[4 * q + 3]);
-          }
+        for (int q = 0; q < FILM_NB / 4; ++q) {
+          const f32x4 gv = gp[q];
+          acc[4 * q + 0] = fmaf(w[u], gv[0], acc[4 * q + 0]);
+          acc[4 * q + 1] = fmaf(w[u], gv[1], acc[4 * q + 1]);
+          acc[4 * q + 2] = fmaf(w[u], gv[2], acc[4 * q + 2]);
+          acc[4 * q + 3] = fmaf(w[u], gv[3], acc[4 * q + 3]);
         }
       }
-      const float bias = a.bias[r];
+    }
+  }
+  if (wv > 0) {
 #pragma unroll
-      for (int k = 0; k < FILM_NB; ++k)
-        if (k < nb) a.film[(size_t)(b0 + k) * a.R + r] = acc[k] + bias;
+    for (int k = 0; k < FILM_NB; ++k) red[((wv - 1) * 64 + lane) * (FILM_NB + 1) + k] = acc[k];
+  }
+  __syncthreads();
+  if (wv == 0 && r < a.R) {
+    const float bias = a.bias[r];
+#pragma unroll
+    for (int k = 0; k < FILM_NB; ++k) {
+      float v = acc[k];
+#pragma unroll
+      for (int w2 = 0; w2 < 3; ++w2) v += red[(w2 * 64 + lane) * (FILM_NB + 1) + k];  // fixed order
+      if (k < nb) a.film[(size_t)(b0 + k) * a.R + r] = v + bias;
     }
   }
 }
@@ -478,8 +493,16 @@ int launch_gelu_rows(const float* in, float* out, int n, hipStream_t st) {
 }
 
 int launch_film(const FilmArgs& a, int B, hipStream_t st) {
-  if (a.E > 1024 || a.E < 8 || a.E % 8) VQVS_FAIL(-1, "film: unsupported E=%d", a.E);
-  hipLaunchKernelGGL(film_kernel, dim3((a.R + 127) / 128), dim3(128), 0, st, a, B);
+  if (a.E > 1024 || a.E < 32 || a.E % 32) VQVS_FAIL(-1, "film: unsupported E=%d", a.E);
+  const int lds = (a.E * FILM_NB + 3 * 64 * (FILM_NB + 1)) * 4;  // <= 153 KiB at E = 1024 (the attribute below covers it)
+  static std::atomic<bool> attr_done[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!attr_done[dev].load(std::memory_order_acquire)) {
+    VQVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&film_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done[dev].store(true, std::memory_order_release);
+  }
+  hipLaunchKernelGGL(film_kernel, dim3((a.R + 63) / 64, (B + FILM_NB - 1) / FILM_NB), dim3(256), lds, st, a, B);
   VQVS_HIP(hipGetLastError());
   return 0;
 }
