@@ -62,6 +62,25 @@ void run(const char* name, const char* d, unsigned* sink, unsigned region, unsig
          per_wg / 1e9, per_wg * grid / 1e12);
 }
 
+// reference point of DESIGN.md section 6: a plain 16-byte-per-lane copy (1 GiB -> 1 GiB), the "6.29 TB/s" of MI355X_MICROARCH.md
+__global__ __launch_bounds__(256) void copy16(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+void run_copy(char* d, int blocks_per_cu) {
+  const size_t n = (1ull << 30) / 16;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  hipLaunchKernelGGL(copy16, dim3(256 * blocks_per_cu), dim3(256), 0, 0, (const u32x4*)d, (u32x4*)(d + (1ull << 30)), n);
+  (void)hipEventRecord(e0);
+  for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(copy16, dim3(256 * blocks_per_cu), dim3(256), 0, 0, (const u32x4*)d, (u32x4*)(d + (1ull << 30)), n);
+  (void)hipEventRecord(e1);
+  (void)hipEventSynchronize(e1);
+  float ms;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  printf("  plain 16-byte copy, %2d blocks of 256 per CU: %6.2f TB/s (read + written)\n", blocks_per_cu, 2.0 * (double)(1ull << 30) * 5 / (ms * 1e-3) / 1e12);
+}
+
 int main() {
   char* d;
   unsigned* sink;
@@ -69,6 +88,8 @@ int main() {
   (void)hipMalloc(&d, total);
   (void)hipMalloc(&sink, 256 * 1024 * 4);
   (void)hipMemset(d, 1, total);
+  printf("# plain copy on this box (the calibration point for every TB/s figure of this round)\n");
+  for (int bpc : {4, 8, 16, 32}) run_copy(d, bpc);
   printf("# tools/ubench/l2_inbound: inbound bytes per CU by source and fetch path (one 16-wave workgroup per CU)\n");
   for (int grid : {1, 32, 256}) {
     for (int nw : {4, 8, 16}) {
