@@ -378,7 +378,6 @@ __global__ __launch_bounds__(ROWS * 4) void conv_ws_kernel(const WsArgs a) {
       nx = fetch(lseg + 1 == a.nseg ? 0 : lseg + 1);
     };
     enter();
-    sync_lds();  // (the first clip's (scale, shift) table is visible to every producer wave; the consumers match this barrier)
     auto prepare = [&]() -> Prep {
       Prep pr = cur;
       pr.meta = cur_valid | (unsigned)(cur_xf | (cur_avg << 4) | (cur_edge << 5));
@@ -582,8 +581,10 @@ __global__ __launch_bounds__(ROWS * 4) void conv_ws_kernel(const WsArgs a) {
       issue(R1, p1);
       const Prep p2 = prepare();
       issue(R2, p2);
-
     }
+    // The first clip's (scale, shift) table -- copied above, or built by the consumer waves (fused GroupNorm) -- is visible from
+    // here; the consumers match this barrier.  The first three chunk loads are already in flight behind it.
+    sync_lds();
     int q = 0;
     WS_TMARK(2)
 #define WS_PBODY(R)              \
