@@ -20,8 +20,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
   timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o pmc -- python $GRAFT_REPO_ROOT/tools/profile_ops.py --precision $PREC --reps 1 > /tmp/pmc_$c.log 2>&1
 done
-NK=$(python -c "print(open('$OUT/ops_unet64_$PREC.txt').read().split(' kernels')[0].split()[-1])")
-NKERNELS=$NK python $GRAFT_REPO_ROOT/tools/pmc_per_op.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE > $OUT/pmc_traffic_per_op_unet64_$PREC.csv
+NKERNELS=auto python $GRAFT_REPO_ROOT/tools/pmc_per_op.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE > $OUT/pmc_traffic_per_op_unet64_$PREC.csv
 head -3 $OUT/pmc_traffic_per_op_unet64_$PREC.csv
 # issue-side counters per op (MFMA busy cycles, VALU / SALU / LDS instruction counts, LDS bank conflicts, wait cycles), two more passes
 i=0
@@ -30,6 +29,6 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   i=$((i+1)); rm -rf /tmp/pmc_s$i
   timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc_s$i -o pmc -- python $GRAFT_REPO_ROOT/tools/profile_ops.py --precision $PREC --reps 1 > /tmp/pmc_s$i.log 2>&1 || tail -3 /tmp/pmc_s$i.log
 done
-NKERNELS=$NK python $GRAFT_REPO_ROOT/tools/pmc_per_op.py /tmp/pmc_s1 /tmp/pmc_s2 > $OUT/pmc_per_op_unet64_$PREC.csv
+NKERNELS=auto python $GRAFT_REPO_ROOT/tools/pmc_per_op.py /tmp/pmc_s1 /tmp/pmc_s2 > $OUT/pmc_per_op_unet64_$PREC.csv
 head -3 $OUT/pmc_per_op_unet64_$PREC.csv
 fi

@@ -17,6 +17,7 @@
 // LDS rows are 64 B (32 channels) with the 16-byte column XOR-swizzled by bits 2..3 of the row, for activations (written by
 // ds_write_b128) and weights (lane-linear DMA image, swizzle applied to the source address) alike: ds_read_b128 conflict-free.
 #include <atomic>
+#include <cstddef>
 #include <cstdlib>
 
 #include "kernels.hpp"
@@ -168,6 +169,7 @@ struct WsArgs {
   int ss_ring;     // 2 or 4 (power of two): clips whose chunks can be in flight at once
   int rev;         // 1: the launch walks its tiles from the last to the first (ConvArgs.rev)
 };
+static_assert(offsetof(WsArgs, gn) == 0, "gn_table reads WsGn through the kernarg segment pointer: it must stay the first member");
 #define WS_SEGF(s, f) ((s) == 0 ? a.seg[0].f : ((s) == 1 ? a.seg[1].f : ((s) == 2 ? a.seg[2].f : a.seg[3].f)))
 
 struct TileCo {
