@@ -12,7 +12,7 @@ from vq_voice_swap_amd import _native
 from vq_voice_swap_amd.unet import ResBlockModule
 from vq_voice_swap_amd.det_init import det_init_
 
-P_PH = ["wait loads (vmcnt)", "prologue + ds_write", "issue next loads", "lgkmcnt + barrier"]
+P_PH = ["wait loads (vmcnt)", "prologue + ds_write", "load cursor (prepare)", "lgkmcnt + barrier", "issue next loads"]
 C_PH = ["tile start: store + bias", "weight DMA issue", "ds_read + MFMA", "tile end: stats/round/LDS", "vmcnt + barrier"]
 L = _native.lib()
 L.vqvs_debug_ws_timing.argtypes = [C.c_void_p, C.c_int]
@@ -42,9 +42,11 @@ def run(cin, cout, Lx, B, prec="fp16", dil=2, emb=256):
         print(f"--- ResBlock {cin}->{cout} L={Lx}: not on the wave-specialised kernel")
         return
     print(f"--- ResBlock {cin}->{cout} L={Lx} B={B} {prec} d={dil} (both convs): {steps / pw:.0f} steps, {tiles / max(cw, 1):.1f} tiles per sampled wave")
-    ptot, ctot = sum(t[0:4]), sum(t[8:13])
+    if t[21]:
+        print(f"   clock: {t[20] / t[21] * 100:.0f} MHz (s_memtime ticks per 100 MHz s_memrealtime tick, sampled consumer waves); {t[21] / cw / 100:.1f} us per sampled workgroup")
+    ptot, ctot = sum(t[0:5]), sum(t[8:13])
     print(f"   producers: {ptot / steps:8.0f} ticks per step")
-    for name, v in zip(P_PH, t[0:4]):
+    for name, v in zip(P_PH, t[0:5]):
         print(f"      {name:28s} {v / steps:8.0f}  {100 * v / ptot:5.1f}%")
     if cw == 0:  # (an ablation build whose consumers only keep the barriers)
         return

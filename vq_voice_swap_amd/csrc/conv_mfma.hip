@@ -22,6 +22,7 @@
 //                hi*hi + lo*hi + hi*lo with fp32 accumulation (drops only lo*lo ~ 2^-18).
 //   epilogue   : accumulators -> LDS -> whole rows: [GELU (ConvMFCCEncoder)] + identity skip | x gelu'(u) (guidance backward),
 //                tile statistics for the next GroupNorm (or its backward), one rounding to the storage type, coalesced stores.
+#include <cstdio>
 #include <cstdlib>
 
 #include <atomic>
@@ -787,6 +788,10 @@ int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st) {
     if (r != 0) return r < 0 ? r : 0;
   }
   if (a.gn != nullptr) VQVS_FAIL(-1, "conv: a fused GroupNorm is only taken where ws_fuses_gn() says so (Cout=%d)", a.Cout);
+  static const int trace = getenv("VQVS_WS_TRACE") ? atoi(getenv("VQVS_WS_TRACE")) : 0;  // (which launches conv_ws_kernel declined)
+  if (trace)
+    fprintf(stderr, "conv_mfma: Cout=%d Lout=%d nseg=%d seg0(C=%d taps=%d dil=%d rsz=%d xf=%d) skip=%d epi_gelu=%d nbw=%d out_f32=%d prec=%d\n", a.Cout, a.Lout,
+            a.nseg, a.seg[0].C, a.seg[0].ntaps, a.seg[0].dil, a.seg[0].resize, a.seg[0].ss != nullptr, a.skip != nullptr, a.epi_gelu, a.nbw, a.out_f32, precision);
   if (a.tile_rows != TT_MAX - 2 * dmax) VQVS_FAIL(-1, "conv: tile_rows %d does not match dilation %d (only conv_ws_kernel has a 128-row form)", a.tile_rows, dmax);
   if (precision == 0) return launch_p<float, true>(a, B, st, wide, big_halo, dmax);
   if (precision == 2) return launch_p<half_t, false>(a, B, st, wide, big_halo, dmax);

@@ -130,8 +130,9 @@ struct WsSeg {
   int dil;           // dilation of a 3-tap segment, else 0: LDS row 0 holds time t0 - dil
   int rsz;           // RESIZE_*: staged row t is source row t (NONE), t >> 1 (UP2: nearest, unet.py:304-305), or the mean of source
                      // rows 2t and 2t + 1 AFTER the prologue (AVG2: avg_pool1d(2), unet.py:300-303)
-  int ss_stride, ss_c0;
   int ss_lds;        // byte offset of this segment's (scale, shift) pairs in the per-clip LDS table
+  // (everything above is what a producer wave prefetches per segment: 48 contiguous bytes = one s_load_dwordx8 + one s_load_dwordx4)
+  int ss_stride, ss_c0;
   int wbase, wstep;  // byte offset of chunk 0's packed weights [tap][Cout][32], bytes per chunk
   int lds_off;       // resident-weights form: byte offset of chunk 0's image in the resident block
 };
@@ -249,6 +250,7 @@ __global__ __launch_bounds__(ROWS * 4) void conv_ws_kernel(const WsArgs a) {
 #ifdef VQVS_TIMING
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tlast = __builtin_amdgcn_s_memtime();
+  const unsigned long long t_sh0 = tlast, t_rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
 
   // Tile range of this workgroup.  Workgroup w runs on XCD w % 8 (observed, used for speed only): every XCD gets one contiguous
@@ -596,8 +598,9 @@ __global__ __launch_bounds__(ROWS * 4) void conv_ws_kernel(const WsArgs a) {
     acquire(R);                  \
     WS_TMARK(0)                  \
     stage(R, q & 1);             \
-    issue(R, pr);                \
     WS_TMARK(1)                  \
+    issue(R, pr);                \
+    WS_TMARK(4)                  \
     sync_lds();                  \
     WS_TMARK(3)                  \
   }                              \
@@ -612,7 +615,7 @@ __global__ __launch_bounds__(ROWS * 4) void conv_ws_kernel(const WsArgs a) {
     sync_lds();  // the consumers' last step
 #ifdef VQVS_TIMING
     if (lane == 0 && ((int)blockIdx.x & 15) == 3) {
-      for (int i = 0; i < 4; ++i) atomicAdd(&g_ws_timing[i], tacc[i]);
+      for (int i = 0; i < 5; ++i) atomicAdd(&g_ws_timing[i], tacc[i]);
       atomicAdd(&g_ws_timing[16], 1ull);
       atomicAdd(&g_ws_timing[18], (unsigned long long)Q);
     }
@@ -946,14 +949,10 @@ __global__ __launch_bounds__(ROWS * 4) void conv_ws_kernel(const WsArgs a) {
                 const V8 a1l = *reinterpret_cast<const V8*>(sb + ACT_BYTES + ao + 32 * 64);
                 acc[0][nt] = ws_mfma(a0, bf, acc[0][nt]);
                 acc[MT - 1][nt] = ws_mfma(a1, bf, acc[MT - 1][nt]);
-                if (!(VQVS_WS_EXP & 8192)) {
                 acc[0][nt] = ws_mfma(a0l, bf, acc[0][nt]);
                 acc[MT - 1][nt] = ws_mfma(a1l, bf, acc[MT - 1][nt]);
-                }
-                if (!(VQVS_WS_EXP & 16384)) {
                 acc[0][nt] = ws_mfma(a0, bl, acc[0][nt]);
                 acc[MT - 1][nt] = ws_mfma(a1, bl, acc[MT - 1][nt]);
-                }
               } else if (VQVS_WS_EXP & 4096) {  // ablation: the fragment reads stay, the MFMAs go
                 asm volatile("" ::"v"(a0), "v"(a1), "v"(bf));
               } else {
@@ -1159,6 +1158,8 @@ __global__ __launch_bounds__(ROWS * 4) void conv_ws_kernel(const WsArgs a) {
     WS_TMARK(0)
     if (lane == 0 && ((int)blockIdx.x & 15) == 3) {
       for (int i = 0; i < 5; ++i) atomicAdd(&g_ws_timing[8 + i], tacc[i]);
+      atomicAdd(&g_ws_timing[20], __builtin_amdgcn_s_memtime() - t_sh0);      // shader-clock ticks of this workgroup ...
+      atomicAdd(&g_ws_timing[21], __builtin_amdgcn_s_memrealtime() - t_rt0);  // ... and 100 MHz ticks: their ratio is the clock it ran at
       atomicAdd(&g_ws_timing[17], 1ull);
       atomicAdd(&g_ws_timing[19], (unsigned long long)(te - tb));
     }
@@ -1292,9 +1293,6 @@ bool ws_plan(const ConvArgs& a, int B, int precision, WsPlan& plan) {
   static const int f32_env = getenv("VQVS_WS_F32") ? atoi(getenv("VQVS_WS_F32")) : 1;  // 0: the fp32 mode stays on conv_mfma_kernel (A/B)
   if (!ws_enabled() || (x3 && (!a.ws_f32 || !f32_env || a.w_lo == nullptr || a.Cout % 64 != 0))) return 0;
   const int es = x3 ? 4 : 2;
-  if (x3 && f32_env == 2 && a.skip != nullptr) return 0;  // (debug: only launches without / with an identity skip)
-  if (x3 && f32_env == 3 && a.skip == nullptr) return 0;
-  if (x3 && f32_env == 4 && a.seg[0].ss != nullptr) return 0;
   if (a.Cout % 32 != 0 || a.out_f32 || a.epi_gelu || a.nbw || (a.out_rows != 0 && a.out_rows != a.Lout)) return 0;
   // rows per clip a source must have for a given resize (kernels.hpp RESIZE_*)
   auto len_ok = [&](int rsz, int Lsrc) { return rsz == RESIZE_UP2 ? Lsrc * 2 == a.Lout : (rsz == RESIZE_AVG2 ? Lsrc / 2 == a.Lout : Lsrc == a.Lout); };
