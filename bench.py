@@ -25,6 +25,9 @@ Rank 0 prints ONE JSON line.  Extra objects:
                  sample of the same workload, extrapolated to 50 steps.  Reported baseline, not the target.
 """
 import argparse
+
+import os
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # kernel arguments in device memory (vq_voice_swap_amd/__init__.py), before the HIP runtime starts
 import csv
 import json
 import os
