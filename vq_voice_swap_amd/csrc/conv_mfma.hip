@@ -744,6 +744,10 @@ int launch_p(const ConvArgs& a, int B, hipStream_t st, bool wide, bool big_halo,
 int conv_tile_rows(int dmax, int Cout, int precision, bool ws_ok) {
   static const int on = getenv("VQVS_WS_ROWS128") ? atoi(getenv("VQVS_WS_ROWS128")) : 0;
   if (on && ws_ok && precision != 0 && Cout == 64 && 128 - 2 * dmax >= 64) return 128 - 2 * dmax;
+  // fp32 storage, 128 output channels and up: the 128-row x 128-channel tile of conv_ws_kernel (every row transformed once per 128
+  // output channels); not where the dilation's halo or the rounding of short clips to 124-row tiles would eat the gain
+  static const int tall = getenv("VQVS_WS_TALL") ? atoi(getenv("VQVS_WS_TALL")) : 1;  // 0: off; 2: at 512 channels too (A/B)
+  if (tall && ws_ok && precision == 0 && Cout % 128 == 0 && (Cout <= 256 || tall >= 2) && dmax <= 2) return 128 - 2 * dmax;
   return TT_MAX - 2 * dmax;
 }
 

@@ -204,22 +204,31 @@ __device__ unsigned long long g_ws_timing[32];
 // Geometry (template): ROWS staged rows per tile (256: one workgroup of 16 waves per CU; 128: 8 waves, two workgroups per CU whose
 // barriers, bookkeeping and tile epilogues interleave), CT output channels per tile (32 / 64 / 128).  ROWS / 32 producer waves (a
 // thread stages two rows x eight channels of every chunk) and as many consumer waves, each owning MT x 32 rows by WN x 32 channels.
+// fp32 storage comes in two geometries, both with 16 waves: 256 rows x 64 channels, and TALL = 128 rows x 128 channels for the
+// levels from 128 output channels up -- the same 32 accumulator registers per consumer wave, but every row is loaded, transformed
+// and split ONCE per 128 output channels instead of once per 64 (a producer thread then stages one row of a chunk, not two).
+template <typename T, int ROWS>
+constexpr int ws_threads() { return sizeof(T) == 4 ? 1024 : ROWS * 4; }
 template <typename T, int ROWS, int CT, bool RES, bool AVG>
-__global__ __launch_bounds__(ROWS * 4) void conv_ws_kernel(const WsArgs a) {
-  constexpr int WN = CT == 128 ? 2 : 1;   // 32-channel MFMA tiles per consumer wave
+__global__ __launch_bounds__((ws_threads<T, ROWS>())) void conv_ws_kernel(const WsArgs a) {
+  constexpr bool X3 = sizeof(T) == 4;     // fp32 storage: hi / lo bf16 planes of activations and weights, three MFMAs per product
+  constexpr bool TALL = X3 && ROWS == 128;
+  constexpr int WN = (CT == 128 && !TALL) ? 2 : 1;  // 32-channel MFMA tiles per consumer wave
   constexpr int MT = CT == 32 ? 1 : 2;    // 32-row MFMA tiles per consumer wave
   constexpr int RW = 32 * MT;             // rows per consumer wave
   constexpr int NWT = ROWS / RW;          // consumer waves along time ...
-  constexpr int NWC = CT == 32 ? 1 : 2;   // ... and along channels
-  constexpr int NCW = NWT * NWC;          // consumer waves = producer waves = ROWS / 32
+  constexpr int NWC = CT / (WN * 32);     // ... and along channels
+  constexpr int NCW = NWT * NWC;          // consumer waves = producer waves (ROWS / 32; 8 in the TALL geometry)
   constexpr int NPT = NCW * 64;           // producer threads (= consumer threads)
-  constexpr int HR = ROWS / 2;            // distance between the two rows a producer thread stages
+  constexpr int PR = ROWS * 4 / NPT;      // rows a producer thread stages per chunk (2; TALL: 1)
+  constexpr int HR = ROWS / 2;            // PR == 2: distance between the two rows a producer thread stages
   constexpr bool DB = CT == 32;           // a tile may be ONE chunk (32 x 3 -> 32): out-tile and statistics are double-buffered
-  constexpr bool X3 = sizeof(T) == 4;     // fp32 storage: hi / lo bf16 planes of activations and weights, three MFMAs per product
   constexpr int ES = (int)sizeof(T);
-  constexpr bool L4 = AVG || X3;          // four loads per thread and chunk (two source rows per staged row, or 32-byte octets)
+  constexpr bool L4 = AVG || (X3 && !TALL);  // four loads per thread and chunk (two source rows per staged row, or two rows of 32-byte octets)
   static_assert(!(AVG && X3), "avg-pooled segments are not built for fp32 storage");
-  static_assert(!X3 || (CT == 64 && ROWS == 256), "fp32 storage: 256 x 64 tiles only");
+  static_assert(!X3 || (CT == 64 && ROWS == 256) || (CT == 128 && ROWS == 128), "fp32 storage: 256 x 64 or 128 x 128 tiles");
+  static_assert(PR == 1 || PR == 2, "producer rows per chunk");
+  static_assert(!TALL || !RES, "the 128 x 128 fp32 tile streams its weights (two planes of 3 x 128 x 64 B per chunk)");
   constexpr int ACT_BYTES = ROWS * 64;    // staged rows x 32 channels (one bf16 / fp16 plane)
   constexpr int W_BYTES = 3 * CT * 64;    // ... of weights
   constexpr int ACT2 = (X3 ? 2 : 1) * ACT_BYTES, W2 = (X3 ? 2 : 1) * W_BYTES;  // [hi plane][lo plane]
@@ -418,7 +427,7 @@ __global__ __launch_bounds__(ROWS * 4) void conv_ws_kernel(const WsArgs a) {
       r.ssaddr = pr.ssaddr;
       if (VQVS_WS_EXP & 1) {
         asm volatile("" : "=v"(r.a0), "=v"(r.a1));  // (opaque garbage, so that nothing downstream folds away)
-        if constexpr (L4) asm volatile("" : "=v"(r.b0), "=v"(r.b1));
+        if constexpr (L4 || TALL) asm volatile("" : "=v"(r.b0), "=v"(r.b1));
         return;
       }
       // (the descriptor is wave-uniform by construction; say so, or the compiler may hand the assembly a VGPR copy of it when it
@@ -426,7 +435,15 @@ __global__ __launch_bounds__(ROWS * 4) void conv_ws_kernel(const WsArgs a) {
       i32x4 rs;
 #pragma unroll
       for (int i = 0; i < 4; ++i) rs[i] = __builtin_amdgcn_readfirstlane(pr.rs[i]);
-      if constexpr (L4) {
+      if constexpr (TALL) {
+        const int ob0 = pr.off0 + 16;
+        asm volatile(
+            "s_nop 4\n\t"
+            "buffer_load_dwordx4 %0, %2, %4, 0 offen\n\t"
+            "buffer_load_dwordx4 %1, %3, %4, 0 offen"
+            : "=&v"(r.a0), "=&v"(r.b0)
+            : "v"(pr.off0), "v"(ob0), "s"(rs));
+      } else if constexpr (L4) {
         const int ob0 = pr.off0 + pr.db, ob1 = pr.off1 + pr.db;
         asm volatile(
             "s_nop 4\n\t"
@@ -449,6 +466,8 @@ __global__ __launch_bounds__(ROWS * 4) void conv_ws_kernel(const WsArgs a) {
       if (VQVS_WS_EXP & 1) return;
       if constexpr (L4)
         asm volatile("s_waitcnt vmcnt(8)" : "+v"(r.a0), "+v"(r.a1), "+v"(r.b0), "+v"(r.b1));
+      else if constexpr (TALL)
+        asm volatile("s_waitcnt vmcnt(4)" : "+v"(r.a0), "+v"(r.b0));
       else
         asm volatile("s_waitcnt vmcnt(4)" : "+v"(r.a0), "+v"(r.a1));
     };
@@ -513,9 +532,12 @@ __global__ __launch_bounds__(ROWS * 4) void conv_ws_kernel(const WsArgs a) {
       if constexpr (X3) {
         // fp32 rows: exact-erf GELU of the affine (common.hpp gelu_f), then the bf16 hi / lo planes of the result
         const f32x4 fa0 = __builtin_bit_cast(f32x4, r.a0), fb0 = __builtin_bit_cast(f32x4, r.b0);
-        const f32x4 fa1 = __builtin_bit_cast(f32x4, r.a1), fb1 = __builtin_bit_cast(f32x4, r.b1);
         f32x8 v0 = {fa0[0], fa0[1], fa0[2], fa0[3], fb0[0], fb0[1], fb0[2], fb0[3]};
-        f32x8 v1 = {fa1[0], fa1[1], fa1[2], fa1[3], fb1[0], fb1[1], fb1[2], fb1[3]};
+        f32x8 v1 = v0;  // (PR == 1: unused)
+        if constexpr (PR == 2) {
+          const f32x4 fa1 = __builtin_bit_cast(f32x4, r.a1), fb1 = __builtin_bit_cast(f32x4, r.b1);
+          v1 = f32x8{fa1[0], fa1[1], fa1[2], fa1[3], fb1[0], fb1[1], fb1[2], fb1[3]};
+        }
         if ((um & 1) && !(VQVS_WS_EXP & 8)) {
           const f32x4* const sp = reinterpret_cast<const f32x4*>(smem + r.ssaddr);
           const f32x4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
@@ -524,7 +546,7 @@ __global__ __launch_bounds__(ROWS * 4) void conv_ws_kernel(const WsArgs a) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             v0[e] = gelu_f(fmaf(v0[e], sc[e], sh[e]));
-            v1[e] = gelu_f(fmaf(v1[e], sc[e], sh[e]));
+            if constexpr (PR == 2) v1[e] = gelu_f(fmaf(v1[e], sc[e], sh[e]));
           }
         }
         if (um & 32) {  // (edge tiles: rows outside the clip are the convolution's zero padding)
@@ -532,16 +554,19 @@ __global__ __launch_bounds__(ROWS * 4) void conv_ws_kernel(const WsArgs a) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             v0[e] *= m0;
-            v1[e] *= m1;
+            if constexpr (PR == 2) v1[e] *= m1;
           }
         }
-        bf16x8 h0, l0, h1, l1;
+        bf16x8 h0, l0;
         split_bf16(v0, h0, l0);
-        split_bf16(v1, h1, l1);
         *reinterpret_cast<bf16x8*>(sb + dst0) = h0;
         *reinterpret_cast<bf16x8*>(sb + ACT_BYTES + dst0) = l0;
-        *reinterpret_cast<bf16x8*>(sb + dst0 + HR * 64) = h1;
-        *reinterpret_cast<bf16x8*>(sb + ACT_BYTES + dst0 + HR * 64) = l1;
+        if constexpr (PR == 2) {
+          bf16x8 h1, l1;
+          split_bf16(v1, h1, l1);
+          *reinterpret_cast<bf16x8*>(sb + dst0 + HR * 64) = h1;
+          *reinterpret_cast<bf16x8*>(sb + ACT_BYTES + dst0 + HR * 64) = l1;
+        }
       } else {
       u32x4 o0 = r.a0, o1 = r.a1;
       if ((um & 1) && !(VQVS_WS_EXP & 8)) {
@@ -711,8 +736,6 @@ __global__ __launch_bounds__(ROWS * 4) void conv_ws_kernel(const WsArgs a) {
     };
     const int gn_ahead = a.gn.nsrc > 0 ? (a.ss_ring >> 1) * (a.rev ? -1 : 1) : 0;  // clips between a table's construction and its clip
     int gn_clip = -1;  // clip at whose first step the last table was built
-    if (a.gn.nsrc > 0)
-      for (int i = 0; i < (a.ss_ring >> 1); ++i) gn_table(first.b + (a.rev ? -i : i));
 
     auto dma = [&](int ntaps, int woff, const TileCo& t, int slot) {  // weights of a chunk -> stage `slot`, 1 KiB (16 rows) per wave-instruction
       if (!RES && ntaps == 0) write_consts(WS_OFF + slot * WS_STRIDE);
@@ -834,11 +857,15 @@ __global__ __launch_bounds__(ROWS * 4) void conv_ws_kernel(const WsArgs a) {
         d_woff += dw.wstep;
       }
     };
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the first tables of a fused GroupNorm are in LDS: the producers read them next)
-    __builtin_amdgcn_s_barrier();  // (pairs with the producers' barrier behind their first (scale, shift) table)
+    // the first chunk's weights are requested before anything this workgroup has to wait for (the tables of a fused GroupNorm,
+    // the producers' first barrier): their latency passes behind both
     dma(dw.ntaps, d_woff, nt_, 0);
     int ntaps = dw.ntaps, d = dw.dil, wb = wlds(0);  // current chunk
     dma_advance();
+    if (a.gn.nsrc > 0)
+      for (int i = 0; i < (a.ss_ring >> 1); ++i) gn_table(first.b + (a.rev ? -i : i));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the first tables of a fused GroupNorm are in LDS: the producers read them next)
+    __builtin_amdgcn_s_barrier();  // (pairs with the producers' barrier behind their first (scale, shift) table)
     float bj[WN];
     int bias_ty = -1;
     // (k-step 1 = the same address with bit 5 flipped: the swizzle XORs the 16-byte column index.  The WPE instantiation has no
@@ -1198,13 +1225,13 @@ int ws_num_cus() {
 
 // LDS bytes besides resident weights and the (scale, shift) ring (the kernel's layout constants, restated for the planner)
 constexpr int ws_fixed_lds(int rows, int ct, bool res, bool x3 = false) {
-  const int ncw = rows / 32, nwt = ct == 32 ? rows / 32 : rows / 64, db = ct == 32 ? 2 : 1, pl = x3 ? 2 : 1;
+  const int ncw = rows / 32, nwt = ct == 32 ? rows / 32 : rows / 64, db = ct == 32 ? 2 : 1, pl = x3 ? 2 : 1;  // (x3: ncw is unused)
   const int obytes = x3 ? 0 : ((res && ct == 128) ? ncw * 2048 : (rows / 2) * (ct * 4 + 16));
   return (res ? 2 * pl * rows * 64 : 2 * pl * (rows * 64 + 3 * ct * 64)) + db * obytes + db * nwt * ct * 8 + (res ? 4096 : 0);
 }
 constexpr int WS_LDS_MAX = 160 * 1024;
 // LDS one workgroup may use: two workgroups of the 128-row geometry share a CU
-constexpr int ws_lds_cap(int rows) { return rows == 256 ? WS_LDS_MAX : WS_LDS_MAX / 2; }
+constexpr int ws_lds_cap(int rows, bool x3 = false) { return (rows == 256 || x3) ? WS_LDS_MAX : WS_LDS_MAX / 2; }
 
 template <typename T, int ROWS, int CT, bool RES, bool AVG>
 int ws_launch(const WsArgs& w, hipStream_t st) {
@@ -1213,13 +1240,14 @@ int ws_launch(const WsArgs& w, hipStream_t st) {
   static std::atomic<bool> attr_done[WS_MAX_DEV];  // (per instantiation and device; setting it twice from two threads is harmless)
   const int dev = ws_cur_dev();
   if (!attr_done[dev].load(std::memory_order_acquire)) {
-    VQVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<T, ROWS, CT, RES, AVG>), hipFuncAttributeMaxDynamicSharedMemorySize, ws_lds_cap(ROWS)));
+    VQVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<T, ROWS, CT, RES, AVG>), hipFuncAttributeMaxDynamicSharedMemorySize, ws_lds_cap(ROWS, X3)));
     attr_done[dev].store(true, std::memory_order_release);
   }
   static const int grid_env = getenv("VQVS_WS_GRID") ? atoi(getenv("VQVS_WS_GRID")) : 0;  // (A/B measurements: workgroups per launch)
-  const int nwg = (grid_env > 0 ? grid_env : ws_num_cus()) * (256 / ROWS);  // persistent workgroups: one (two) per CU
+  constexpr int NT = ws_threads<T, ROWS>();
+  const int nwg = (grid_env > 0 ? grid_env : ws_num_cus()) * (1024 / NT);  // persistent workgroups: one (two) per CU
   const int grid = w.ntiles < nwg ? w.ntiles : nwg;
-  hipLaunchKernelGGL((conv_ws_kernel<T, ROWS, CT, RES, AVG>), dim3(grid), dim3(ROWS * 4), lds, st, w);
+  hipLaunchKernelGGL((conv_ws_kernel<T, ROWS, CT, RES, AVG>), dim3(grid), dim3(NT), lds, st, w);
   VQVS_HIP(hipGetLastError());
   return 0;
 }
@@ -1231,7 +1259,8 @@ int ws_launch_f(const WsArgs& w, bool res, bool avg, hipStream_t st) {
   if (avg) return ws_launch<T, ROWS, CT, false, true>(w, st);
   return res ? ws_launch<T, ROWS, CT, true, false>(w, st) : ws_launch<T, ROWS, CT, false, false>(w, st);
 }
-int ws_launch_f32(const WsArgs& w, bool res, hipStream_t st) {  // fp32 storage: 256 x 64 tiles, no avg-pooled segments
+int ws_launch_f32(const WsArgs& w, int rows, bool res, hipStream_t st) {  // fp32 storage: 256 x 64 or 128 x 128 tiles, no avg-pooled segments
+  if (rows == 128) return res ? -1 : ws_launch<float, 128, 128, false, false>(w, st);
   return res ? ws_launch<float, 256, 64, true, false>(w, st) : ws_launch<float, 256, 64, false, false>(w, st);
 }
 template <typename T>
@@ -1281,7 +1310,7 @@ int launch_conv_ws(const ConvArgs& a, int B, int precision, hipStream_t st) {
   WsPlan plan;
   if (!ws_plan(a, B, precision, plan)) return 0;
   if (a.gn != nullptr && !plan.gn) return 0;  // (the caller launches gn_prepare and comes back without a.gn)
-  const int rc = precision == 0 ? ws_launch_f32(plan.w, plan.res, st)
+  const int rc = precision == 0 ? ws_launch_f32(plan.w, plan.rows, plan.res, st)
                  : precision == 2 ? ws_launch_t<half_t>(plan.w, plan.rows, plan.CT, plan.res, plan.avg, st)
                                   : ws_launch_t<bf16_t>(plan.w, plan.rows, plan.CT, plan.res, plan.avg, st);
   return rc < 0 ? rc : 1;
@@ -1299,7 +1328,12 @@ bool ws_plan(const ConvArgs& a, int B, int precision, WsPlan& plan) {
   if ((long long)a.Lout * a.Cout * es >= (1LL << 31)) return 0;  // (the tile stores go through a 32-bit descriptor of one clip's rows)
   if (a.skip != nullptr && (a.skip_C != a.Cout || !len_ok(a.skip_resize, a.skip_L) || (long long)a.skip_L * a.skip_C * es >= (1LL << 29))) return 0;
   bool avg = a.skip != nullptr && a.skip_resize == RESIZE_AVG2;
-  const int CT = x3 ? 64 : (a.Cout % 128 == 0 ? 128 : (a.Cout % 64 == 0 ? 64 : 32));
+  int dmax0 = 0;
+  for (int s = 0; s < a.nseg; ++s)
+    if (a.seg[s].ntaps == 3 && a.seg[s].dil > dmax0) dmax0 = a.seg[s].dil;
+  // fp32 storage: the schedule builder asks for the 128-row x 128-channel tile through tile_rows (conv_tile_rows)
+  const bool tall = x3 && a.Cout % 128 == 0 && a.tile_rows > 0 && a.tile_rows == 128 - 2 * dmax0;
+  const int CT = x3 ? (tall ? 128 : 64) : (a.Cout % 128 == 0 ? 128 : (a.Cout % 64 == 0 ? 64 : 32));
   plan.w = WsArgs{};
   WsArgs& w = plan.w;
   int dmax = 0, n = 0;
@@ -1348,7 +1382,7 @@ bool ws_plan(const ConvArgs& a, int B, int precision, WsPlan& plan) {
     n += q.nch;
   }
   // the staged window: 256 rows, or 128 (tile_rows = 128 - 2 dmax, chosen by the schedule builder: conv_tile_rows)
-  if (x3 && (avg || a.tile_rows != 256 - 2 * dmax)) return 0;
+  if (x3 && (avg || (!tall && a.tile_rows != 256 - 2 * dmax))) return 0;
   const int rows = a.tile_rows == 256 - 2 * dmax ? 256 : (a.tile_rows == 128 - 2 * dmax && CT >= 64 && a.tile_rows > 0 ? 128 : 0);
   if (rows == 0 || a.w_bytes > 0x7fffffffLL || n < (CT == 32 ? 1 : 2)) return 0;
   plan.rows = rows;
@@ -1374,13 +1408,13 @@ bool ws_plan(const ConvArgs& a, int B, int precision, WsPlan& plan) {
   if (w.ss_bytes > 8192) return 0;  // (one 16-byte piece per producer thread)
   w.ss_ring = (long long)w.ntx * w.nty * n >= 4 ? 2 : 4;
   const int ss_total = w.ss_ring * w.ss_bytes;
-  if (ws_fixed_lds(rows, CT, false, x3) + ss_total > ws_lds_cap(rows)) return 0;
+  if (ws_fixed_lds(rows, CT, false, x3) + ss_total > ws_lds_cap(rows, x3)) return 0;
   // (avg-pooled launches stream their weights: resident weights + four loads per chunk do not fit 128 VGPRs without spills, and
   //  compiler-generated scratch traffic has no place beside the producers' counted waits)
   if (w.ntiles >= (1 << 24)) return 0;  // (the kernel's tile-range arithmetic is 32-bit)
   plan.CT = CT;
   plan.avg = avg;
-  plan.res = res_env && !avg && w.nty == 1 && ws_fixed_lds(rows, CT, true, x3) + (x3 ? 2 : 1) * w.wres_bytes + ss_total <= ws_lds_cap(rows);
+  plan.res = res_env && !avg && !tall && w.nty == 1 && ws_fixed_lds(rows, CT, true, x3) + (x3 ? 2 : 1) * w.wres_bytes + ss_total <= ws_lds_cap(rows, x3);
   if (plan.res && CT == 128 && (long long)a.Lout * CT * 2 >= (1LL << 31)) return 0;  // (the wave-private epilogue's store descriptor covers one clip)
   // GroupNorm built by the producers (WsGn): every prologue segment is one whole source of *a.gn, in order; a group is a power of
   // two of lanes; few enough tile partials per channel that the serial sum at a clip change stays short

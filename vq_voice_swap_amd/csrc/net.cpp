@@ -418,7 +418,19 @@ class Builder {
       if (g.ntaps == 3 && g.dil > dmax) dmax = g.dil;
     int kchunks = skip ? 2 : 0;  // (K chunks of 32 channels per tile: a one-chunk tile is only covered at 32 output channels)
     for (auto& g : segs) kchunks += g.C / 32;
-    const bool ws_ok = !out.f32 && !epi_gelu && fuse == nullptr && out_lshift == -1000 && kchunks >= 2;
+    bool ws_ok = !out.f32 && !epi_gelu && fuse == nullptr && out_lshift == -1000 && kchunks >= 2;
+    if (m_->cfg.precision == VQVS_PREC_F32) {
+      // fp32 storage: a tile geometry other than the default one may only be chosen where conv_ws_kernel is certain to take the
+      // launch (conv_mfma_kernel has one geometry): its fp32 form has no avg-pooled sources, wants 32-channel chunks, and
+      // addresses a clip's rows through 32-bit descriptors -- checked here against the model's largest clip
+      const bool kind_ok = m_->cfg.kind == VQVS_KIND_PREDICTOR || m_->cfg.kind == VQVS_KIND_RESBLOCK;
+      bool ok = kind_ok && Cout % 64 == 0 && !(skip && skip_resize == RESIZE_AVG2);
+      auto clip_bytes = [&](const TensorH& t) { return (long long)shiftL(m_->cfg.max_T, t.lshift) * t.C * 4; };
+      for (auto& g : segs) ok = ok && g.resize != RESIZE_AVG2 && g.C % 32 == 0 && (g.ntaps == 1 || g.ntaps == 3) && clip_bytes(g.t) < (1LL << 29);
+      if (skip) ok = ok && skip->C == Cout && clip_bytes(*skip) < (1LL << 29);
+      ok = ok && clip_bytes(out) < (1LL << 31);
+      ws_ok = ws_ok && ok;
+    }
     const int tile_rows = conv_tile_rows(dmax, Cout, m_->cfg.precision, ws_ok);
     if (out.has_stats) tile_rows_[out.id] = tile_rows;
     // cost
