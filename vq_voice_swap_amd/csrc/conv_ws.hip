@@ -180,7 +180,7 @@ struct TileCo {
 #ifndef VQVS_WS_EXP
 #define VQVS_WS_EXP 0  // ablation bits for tools/experiments (results are WRONG when non-zero): 1 no activation loads, 2 no weight DMA,
 #endif                // 4 no tile store, 8 no prologue arithmetic, 16 no MFMA loop, 32 no tile-end statistics / rounding, 64 constant
-                      // (scale, shift), 128 no zero masks, 256 store at the step's start, 1024 idle consumers, 2048 trivial load cursor, 4096 fragment reads without MFMAs
+                      // (scale, shift), 128 no zero masks, 256 store at the step's start, 1024 idle consumers, 2048 trivial load cursor, 4096 fragment reads without MFMAs, 32768 no barriers inside the step loop
 
 #ifdef VQVS_TIMING
 __device__ unsigned long long g_ws_timing[32];
@@ -309,7 +309,7 @@ __global__ __launch_bounds__((ws_threads<T, ROWS>())) void conv_ws_kernel(const 
   };
   auto sync_lds = [&]() {  // LDS writes / reads of this wave are done; global loads stay in flight across the barrier
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if (!(VQVS_WS_EXP & 32768)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
 
@@ -754,7 +754,7 @@ __global__ __launch_bounds__((ws_threads<T, ROWS>())) void conv_ws_kernel(const 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       else
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      if (!(VQVS_WS_EXP & 32768)) __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     };
 
@@ -1173,7 +1173,7 @@ __global__ __launch_bounds__((ws_threads<T, ROWS>())) void conv_ws_kernel(const 
         if (!(VQVS_WS_EXP & 4)) store_tile();
         pending = false;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if (!(VQVS_WS_EXP & 32768)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
       } else {
         sync_all();
