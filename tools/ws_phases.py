@@ -1,7 +1,7 @@
 """Where the cycles of the wave-specialised convolution kernel (csrc/conv_ws.hip) go, per role: s_memtime totals from the
 instrumented library (`make -C vq_voice_swap_amd/csrc timing` -> libvqvs_timing.so), for single-ResBlock shapes.
 
-    VQVS_LIB_PATH=vq_voice_swap_amd/libvqvs_timing.so python tools/ws_phases.py ["((cin, cout, L, B), ...)"]
+    VQVS_LIB_PATH=vq_voice_swap_amd/libvqvs_timing.so python tools/ws_phases.py ["((cin, cout, L, B), ...)" [fp16|bf16|fp32]]
 """
 import ast, ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -57,5 +57,6 @@ def run(cin, cout, Lx, B, prec="fp16", dil=2, emb=256):
 
 
 shapes = ast.literal_eval(sys.argv[1]) if len(sys.argv) > 1 else ((64, 64, 64000, 64), (128, 128, 16000, 64), (256, 256, 2000, 64), (512, 512, 250, 64))
+prec = sys.argv[2] if len(sys.argv) > 2 else "fp16"
 for shape in shapes:
-    run(*shape)
+    run(*shape, prec=prec)
