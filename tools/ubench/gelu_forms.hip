@@ -4,15 +4,30 @@
 //   poly7   : Phi = clamp01(0.5 + v p(min(v^2, 16))), p of degree 7 (the fp16 prologue)
 //   poly6   : the same with degree 6 (the bf16 prologue)
 //   sigm3   : Phi = 1 / (1 + exp2(-v q(min(v^2, 36)))), q of degree 2 in v^2 (max |Phi error| 3.1e-5 on the whole line)
+//   table   : Phi by linear interpolation in a 512-entry LDS table of (value, slope) pairs over [-4, 4] (|error| 7e-6):
+//             v_fma + v_med3 + v_floor + v_sub + v_cvt + ds_read_b64 + v_fma + v_mul -- fewer VALU, one LDS read per element
 //   hipcc -O3 --offload-arch=gfx950 gelu_forms.hip -o gelu_forms && ./gelu_forms
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #define SB() __builtin_amdgcn_sched_barrier(0)
 #define G8(expr) _Pragma("unroll") for (int i = 0; i < 8; ++i) { expr; } SB();
 
+__shared__ float2 g_tab[512];
 template <int FORM>
 __device__ __forceinline__ void gelu8(float (&v)[8]) {
   float w[8], p[8];
+  if constexpr (FORM == 7) {
+    int idx[8];
+    float2 e[8];
+    G8(w[i] = __builtin_amdgcn_fmed3f(fmaf(v[i], 64.0f, 256.0f), 0.0f, 511.0f))
+    G8(p[i] = __builtin_floorf(w[i]))
+    G8(w[i] = w[i] - p[i])
+    G8(idx[i] = (int)p[i])
+    G8(e[i] = g_tab[idx[i]])
+    G8(p[i] = fmaf(e[i].y, w[i], e[i].x))
+    G8(v[i] = v[i] * p[i])
+    return;
+  }
   if constexpr (FORM == 0 || FORM == 1) {
     G8(w[i] = v[i] * v[i])
     G8(w[i] = __builtin_fminf(w[i], 16.0f))
@@ -59,11 +74,19 @@ __device__ __forceinline__ void gelu8(float (&v)[8]) {
 template <int FORM>
 __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
   float a[8];
-  for (int i = 0; i < 8; ++i) a[i] = seed * 0.01f * (i + 1) + threadIdx.x * 0.003f - 0.4f;
+  if (FORM == 7) {
+    for (int i = threadIdx.x; i < 512; i += 256) {
+      const float x0 = (i - 256) / 64.0f, x1 = (i - 255) / 64.0f;
+      const float f0 = 0.5f * erfcf(-x0 * 0.70710678f), f1 = 0.5f * erfcf(-x1 * 0.70710678f);
+      g_tab[i] = float2{f0, f1 - f0};
+    }
+    __syncthreads();
+  }
+  for (int i = 0; i < 8; ++i) a[i] = seed * 0.01f * (i + 1) + threadIdx.x * 0.003f - 0.4f + ((threadIdx.x * 37) & 63) * 0.03f;
   for (int it = 0; it < iters; ++it) {
     gelu8<FORM>(a);
     // (keep the values in a sane range without adding more than one cheap instruction per element)
-    if (FORM <= 2) { G8(a[i] = fmaf(a[i], 0.5f, 0.3f)) }
+    if (FORM <= 2 || FORM == 7) { G8(a[i] = fmaf(a[i], 0.5f, 0.3f)) }
   }
   float s = 0;
   for (int i = 0; i < 8; ++i) s += a[i];
@@ -101,6 +124,7 @@ int main() {
     run<0>("gelu poly7 (fp16 prologue)", w, f);
     run<1>("gelu poly6 (bf16 prologue)", w, f);
     run<2>("gelu sigm3 (exp2 + rcp)", w, f);
+    run<7>("gelu table (LDS, linear interp.)", w, f);
   }
   return 0;
 }
