@@ -140,7 +140,11 @@ __device__ __forceinline__ f32x2 gelu2(f32x2 v) {
 template <typename T> struct GeluQ;  // quality level that goes with an activation storage type
 template <> struct GeluQ<float> { static constexpr int q = GELU_EXACT; };
 template <> struct GeluQ<bf16_t> { static constexpr int q = GELU_POLY6; };
+#ifdef VQVS_F16_GELU6
+template <> struct GeluQ<half_t> { static constexpr int q = GELU_POLY6; };
+#else
 template <> struct GeluQ<half_t> { static constexpr int q = GELU_POLY7; };
+#endif
 
 // element load/store of 8 consecutive channels as fp32, for both activation storage types
 template <typename T>

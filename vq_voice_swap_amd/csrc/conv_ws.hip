@@ -34,7 +34,11 @@ template <typename T> struct WsOp;
 template <> struct WsOp<half_t> {
   typedef f16x8 v8;
   static constexpr unsigned short one = 0x3C00;
+#ifdef VQVS_F16_GELU6
+  static constexpr int gq = GELU_POLY6;  // (A/B: the bf16 mode's polynomial in the fp16 mode)
+#else
   static constexpr int gq = GELU_POLY7;
+#endif
 };
 template <> struct WsOp<bf16_t> {
   typedef bf16x8 v8;
