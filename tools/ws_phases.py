@@ -44,6 +44,9 @@ def run(cin, cout, Lx, B, prec="fp16", dil=2, emb=256):
     print(f"--- ResBlock {cin}->{cout} L={Lx} B={B} {prec} d={dil} (both convs): {steps / pw:.0f} steps, {tiles / max(cw, 1):.1f} tiles per sampled wave")
     if t[21]:
         print(f"   clock: {t[20] / t[21] * 100:.0f} MHz (s_memtime ticks per 100 MHz s_memrealtime tick, sampled consumer waves); {t[21] / cw / 100:.1f} us per sampled workgroup")
+    if t[22]:
+        print(f"   startup (ticks per sampled workgroup and launch): entry -> requests out / tables {t[22] / cw:.0f}, -> first barrier {t[23] / cw:.0f}, "
+              f"-> weights landed {t[24] / cw:.0f}, -> loop starts {t[25] / cw:.0f}; whole workgroup {t[20] / cw:.0f}")
     ptot, ctot = sum(t[0:5]), sum(t[8:13])
     print(f"   producers: {ptot / steps:8.0f} ticks per step")
     for name, v in zip(P_PH, t[0:5]):

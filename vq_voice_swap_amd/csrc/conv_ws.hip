@@ -868,8 +868,14 @@ __global__ __launch_bounds__((ws_threads<T, ROWS>())) void conv_ws_kernel(const 
     dma_advance();
     if (a.gn.nsrc > 0)
       for (int i = 0; i < (a.ss_ring >> 1); ++i) gn_table(first.b + (a.rev ? -i : i));
+#ifdef VQVS_TIMING
+    const unsigned long long t_su1 = __builtin_amdgcn_s_memtime();  // (startup marks: requests out, first tables built)
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the first tables of a fused GroupNorm are in LDS: the producers read them next)
     __builtin_amdgcn_s_barrier();  // (pairs with the producers' barrier behind their first (scale, shift) table)
+#ifdef VQVS_TIMING
+    const unsigned long long t_su2 = __builtin_amdgcn_s_memtime();  // (first barrier passed)
+#endif
     float bj[WN];
     int bias_ty = -1;
     // (k-step 1 = the same address with bit 5 flipped: the swizzle XORs the 16-byte column index.  The WPE instantiation has no
@@ -877,7 +883,13 @@ __global__ __launch_bounds__((ws_threads<T, ROWS>())) void conv_ws_kernel(const 
     constexpr int NKS = WPE ? 1 : 2;
     int aoff[3][NKS], aoff_d = -1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // first chunk's (or all resident) weights have landed
+#ifdef VQVS_TIMING
+    const unsigned long long t_su3 = __builtin_amdgcn_s_memtime();  // (weights landed)
+#endif
     sync_all();
+#ifdef VQVS_TIMING
+    const unsigned long long t_su4 = __builtin_amdgcn_s_memtime();  // (loop starts)
+#endif
     WS_TMARK(4)
     if (VQVS_WS_EXP & 1024) {  // ablation: the consumers only keep the barrier count
       for (int g = 0; g < Q; ++g) sync_all();
@@ -1189,6 +1201,10 @@ __global__ __launch_bounds__((ws_threads<T, ROWS>())) void conv_ws_kernel(const 
     WS_TMARK(0)
     if (lane == 0 && ((int)blockIdx.x & 15) == 3) {
       for (int i = 0; i < 5; ++i) atomicAdd(&g_ws_timing[8 + i], tacc[i]);
+      atomicAdd(&g_ws_timing[22], t_su1 - t_sh0);  // startup of the sampled consumer wave: entry -> requests out and tables built,
+      atomicAdd(&g_ws_timing[23], t_su2 - t_su1);  // -> first barrier passed,
+      atomicAdd(&g_ws_timing[24], t_su3 - t_su2);  // -> first weights landed,
+      atomicAdd(&g_ws_timing[25], t_su4 - t_su3);  // -> second barrier passed (the step loop starts)
       atomicAdd(&g_ws_timing[20], __builtin_amdgcn_s_memtime() - t_sh0);      // shader-clock ticks of this workgroup ...
       atomicAdd(&g_ws_timing[21], __builtin_amdgcn_s_memrealtime() - t_rt0);  // ... and 100 MHz ticks: their ratio is the clock it ran at
       atomicAdd(&g_ws_timing[17], 1ull);
