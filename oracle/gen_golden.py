@@ -495,6 +495,84 @@ def gen_conv_mfcc_stack():
     save("f12_conv_mfcc_stack", **out)
 
 
+# ---------------------------------------------------------------- F13: BASELINE config 5 at its own step count
+def gen_guided_unet64_100():
+    """unet64 sampled under classifier32's gradient at every one of 100 steps (BASELINE config 5; reference sample_diffusion.py:34-42
+    + diffusion/diffusion.py:80-83, 92-133), 2 clips x T = 16384, constrain=True.  The cond_fn below is the closure sample_diffusion.py
+    defines inside main() (it cannot be imported), around the reference's own Classifier and autograd."""
+    import torch.nn.functional as F
+    from vq_voice_swap.models import Classifier  # reference
+
+    model = det_model(DiffusionModel("unet", 64))
+    clf = Classifier(num_labels=7, base_channels=32)
+    det_init_(("clf." + k, v) for k, v in clf.state_dict().items())
+    clf.eval()
+    sd_m, sd_c = state_of(model), state_of(clf)
+    T, steps, scale = 16384, 100, 2000.0
+    labels = torch.tensor([1, 6])
+    x_T = seeded((2, 1, T), 151)
+
+    def cond_fn(x, ts):  # sample_diffusion.py:34-42 with labels fixed and args.classifier_scale = scale
+        with torch.enable_grad():
+            x = x.detach().clone().requires_grad_()
+            logits = clf(x, ts)
+            logprobs = F.log_softmax(logits, dim=-1)
+            grads = torch.autograd.grad(logprobs[range(len(x)), labels].sum(), x)[0]
+            return grads.detach() * scale
+
+    gen = torch.Generator().manual_seed(152)
+    noises = [torch.randn(x_T.shape, generator=gen) for _ in range(steps)]
+    it = iter(noises)
+    import vq_voice_swap.diffusion.diffusion as dmod
+    orig = torch.randn_like
+    dmod.torch.randn_like = lambda t, *a, **k: next(it)
+    try:
+        x0 = model.diffusion.ddpm_sample(x_T, model.predictor, steps, constrain=True, cond_fn=cond_fn)
+    finally:
+        dmod.torch.randn_like = orig
+    x0b = ref_cpu.ddpm_sample("exp", x_T, lambda p, q: ref_cpu.unet_predictor(sd_m, 64, p, q), steps, noises, constrain=True,
+                              cond_fn=ref_cpu.classifier_cond_fn(sd_c, 32, labels, scale))
+    check("guided unet64 + classifier32, 100 steps", x0, x0b, tol=1e-5)
+    plain = ref_cpu.ddpm_sample("exp", x_T, lambda p, q: ref_cpu.unet_predictor(sd_m, 64, p, q), steps, noises, constrain=True)
+    eff = (x0 - plain).pow(2).mean().sqrt().item()
+    print(f"  x0 rms={x0.pow(2).mean().sqrt().item():.4f}; guided vs unguided rms={eff:.3e}; saturated={(x0.abs() >= 1).float().mean().item():.3f}")
+    save("f13_guided_unet64_100", x_T_seed=151, noise_seed=152, steps=steps, scale=scale, labels=labels, x0=x0,
+         guidance_effect_rms=eff, noise_checksum=np.array([n.double().sum().item() for n in noises]))
+
+
+# ---------------------------------------------------------------- F8c: BASELINE config 4 at base 64 and its own step count
+def gen_vqvae64_decode50():
+    """VQVAE(base_channels=64).decode (vq_vae.py:92-145), 50 steps, T = 16384, constrain=True: codes -> vq.embed -> conditional unet64."""
+    import vq_voice_swap.diffusion.diffusion as dmod
+    import vq_voice_swap.vq_vae as vmod
+
+    model = det_model(VQVAE(base_channels=64, pred_name="unet", num_labels=7))
+    with torch.no_grad():
+        model.vq.dictionary.copy_(seeded(model.vq.dictionary.shape, 78, 0.35))
+    sd = state_of(model)
+    T, steps = 16384, 50
+    codes = torch.randint(0, 512, (2, T // 256), generator=torch.Generator().manual_seed(141))
+    labels = torch.tensor([2, 5])
+    x_T = seeded((2, 1, T), 142)
+    gen = torch.Generator().manual_seed(143)
+    noises = [torch.randn(x_T.shape, generator=gen) for _ in range(steps)]
+    it = iter(noises)
+    orig_rl, orig_r = torch.randn_like, torch.randn
+    dmod.torch.randn_like = lambda t, *a, **k: next(it)
+    vmod.torch.randn = lambda *a, **k: x_T.clone()
+    try:
+        with torch.no_grad():
+            dec = model.decode(codes, labels, steps=steps, constrain=True)
+    finally:
+        dmod.torch.randn_like = orig_rl
+        vmod.torch.randn = orig_r
+    dec2 = ref_cpu.vqvae_decode(sd, 64, "exp", codes, labels, steps, x_T, noises, constrain=True)
+    check("VQVAE(64) decode 50 steps", dec, dec2, tol=1e-5)
+    print(f"  x0 rms={dec.pow(2).mean().sqrt().item():.4f}; saturated={(dec.abs() >= 1).float().mean().item():.3f}")
+    save("f8c_vqvae64_decode50", x_T_seed=142, noise_seed=143, steps=steps, codes=codes, labels=labels, x0=dec,
+         noise_checksum=np.array([n.double().sum().item() for n in noises]))
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     if not only or "resblocks" in only:
@@ -523,4 +601,8 @@ if __name__ == "__main__":
         gen_conv_mfcc_stack()
     if "unet64" in only:  # (minutes of CPU time: only on request; the committed fixture is re-verifiable with this argument)
         gen_sampler_unet64()
+    if "guided64" in only:  # (BASELINE config 5 at 100 steps: about a minute of CPU time, on request)
+        gen_guided_unet64_100()
+    if "vqvae64" in only:  # (BASELINE config 4 at base 64, 50 steps)
+        gen_vqvae64_decode50()
     print("ok")

@@ -45,7 +45,10 @@ using namespace vqvs;
 extern "C" {
 
 const char* vqvs_last_error(void) { return g_err.c_str(); }
-const char* vqvs_version(void) { return "vqvs-hip 0.1 (gfx950)"; }
+#ifndef VQVS_BUILD_ID
+#define VQVS_BUILD_ID "unstamped"
+#endif
+const char* vqvs_version(void) { return "vqvs-hip 0.1 (gfx950) build " VQVS_BUILD_ID; }  // (build id: hash of the sources, csrc/Makefile)
 
 int vqvs_param_count(const vqvs_cfg* cfg) {
   if (!cfg) VQVS_FAIL(VQVS_ERR_ARG, "cfg is NULL");
