@@ -13,6 +13,8 @@ import math
 import os
 import sys
 
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # kernel arguments in device memory: a process-level HIP switch, set before the runtime starts
+
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

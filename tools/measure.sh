@@ -31,4 +31,13 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
 done
 NKERNELS=auto python $GRAFT_REPO_ROOT/tools/pmc_per_op.py /tmp/pmc_s1 /tmp/pmc_s2 > $OUT/pmc_per_op_unet64_$PREC.csv
 head -3 $OUT/pmc_per_op_unet64_$PREC.csv
+# stamp: the library these counters were collected on (bench.py replays profiles/latest_pmc_* only for the same build id)
+python - > $OUT/pmc_stamp_unet64_$PREC.json <<PY
+import json, sys
+sys.path.insert(0, "$GRAFT_REPO_ROOT")
+from vq_voice_swap_amd import _native
+print(json.dumps({"library": _native.lib().vqvs_version().decode(), "precision": "$PREC", "workload": "unet64 forward, 64 clips x 64000 samples",
+                  "collected_by": "tools/measure.sh: rocprofv3 --pmc, one counter set per pass"}))
+PY
+cat $OUT/pmc_stamp_unet64_$PREC.json
 fi

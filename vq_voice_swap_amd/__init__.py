@@ -2,14 +2,11 @@
 vq_voice_swap_amd: MI355X (gfx950) native DDPM audio sampler behind the
 DiffusionModel / VQVAE API of unixpickle/vq-voice-swap.  See DESIGN.md.
 """
-import os as _os
-
-# Kernel arguments in device memory (a HIP runtime switch, read when the runtime initialises, i.e. at the process's first HIP call):
-# the default on this stack keeps them in host memory, and every launch of the 225-kernel forward then starts with scalar loads across
-# PCIe -- measured 2.3 % of the headline throughput and 3.7 % of a unet32 forward (DESIGN.md section 7, round 4).  Harmless if the
-# runtime is already up (then whatever the process was started with stays in force).
-_os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
-
+# The package does NOT touch process-wide HIP runtime switches.  One of them matters for speed: HIP_FORCE_DEV_KERNARG=1 (kernel
+# arguments in device memory; the default on this stack keeps them in host memory, and every launch of the 225-kernel forward then
+# starts with scalar loads across PCIe: 2.3 % of the headline throughput, DESIGN.md section 7).  It is read when the HIP runtime
+# initialises, so it belongs to the PROCESS: bench.py, the sample_*.py scripts, __graft_entry__.py and tests/conftest.py set it before
+# they import torch; a host application sets it in its own environment (INTEGRATION.md).  _native.lib() warns once when it is unset.
 from .base import Savable, atomic_save
 from .classifier import Classifier
 from .conv_encoder import ConvMFCCEncoder

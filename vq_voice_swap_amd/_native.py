@@ -83,6 +83,12 @@ def lib():
             f"{LIB_PATH} is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C vq_voice_swap_amd/csrc`). There is no CPU fallback for the sampling hot path."
         )
+    if os.environ.get("HIP_FORCE_DEV_KERNARG") is None:
+        import warnings
+
+        warnings.warn("HIP_FORCE_DEV_KERNARG is not set: the HIP runtime keeps kernel arguments in host memory and every launch of the "
+                      "sampler starts with loads across PCIe (~2 % slower, DESIGN.md section 7).  Set HIP_FORCE_DEV_KERNARG=1 in the "
+                      "process environment before the first HIP call (bench.py and the sample_*.py scripts do).", RuntimeWarning, stacklevel=2)
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, u32, u64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_uint64, C.c_float
     L.vqvs_last_error.restype = C.c_char_p

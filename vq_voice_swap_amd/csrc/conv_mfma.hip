@@ -742,6 +742,7 @@ int launch_p(const ConvArgs& a, int B, hipStream_t st, bool wide, bool big_halo,
 // 128 output channels on a workgroup's LDS (weights or out-tile) no longer fits twice into a CU; conv_mfma_kernel has no 128-row
 // form at all.  VQVS_WS_ROWS128 = 0 / 1 (A/B measurements).
 int conv_tile_rows(int dmax, int Cout, int precision, bool ws_ok) {
+  ws_ok = ws_ok && ws_available(precision);  // (the same switches ws_plan obeys: a geometry conv_mfma_kernel lacks is never chosen with them off)
   static const int on = getenv("VQVS_WS_ROWS128") ? atoi(getenv("VQVS_WS_ROWS128")) : 0;
   if (on && ws_ok && precision != 0 && Cout == 64 && 128 - 2 * dmax >= 64) return 128 - 2 * dmax;
   // fp32 storage, 128 output channels and up: the 128-row x 128-channel tile of conv_ws_kernel (every row transformed once per 128

@@ -171,7 +171,7 @@ struct WsArgs {
   int Cout, Lout, TTO, ntx, nty, ntiles, ntiles_stat;
   int wres_bytes;  // resident-weights form: bytes of all segments' weights
   int ss_bytes;    // bytes of one clip's (scale, shift) table (all prologue segments), ss_ring copies of it live in LDS
-  int ss_ring;     // 2 or 4 (power of two): clips whose chunks can be in flight at once
+  int ss_ring;     // 2, 4 or 8 (power of two): clips whose chunks can be in flight at once
   int rev;         // 1: the launch walks its tiles from the last to the first (ConvArgs.rev)
 };
 static_assert(offsetof(WsArgs, gn) == 0, "gn_table reads WsGn through the kernarg segment pointer: it must stay the first member");
@@ -1321,6 +1321,14 @@ struct WsPlan {
 bool ws_plan(const ConvArgs& a, int B, int precision, WsPlan& plan);
 }  // namespace
 
+// The one predicate behind "may the schedule builder pick a geometry only conv_ws_kernel has" (conv_tile_rows) and ws_plan's own
+// switches: with VQVS_WS=0 or (fp32 storage) VQVS_WS_F32=0 every launch must keep conv_mfma_kernel's tile geometry.
+int ws_f32_enabled() {
+  static const int v = getenv("VQVS_WS_F32") ? atoi(getenv("VQVS_WS_F32")) : 1;  // 0: the fp32 mode stays on conv_mfma_kernel (A/B)
+  return v;
+}
+bool ws_available(int precision) { return ws_enabled() != 0 && (precision != 0 || ws_f32_enabled() != 0); }
+
 bool ws_fuses_gn(const ConvArgs& a, int B, int precision) {
   WsPlan plan;
   return a.gn != nullptr && ws_plan(a, B, precision, plan) && plan.gn;
@@ -1339,8 +1347,7 @@ int launch_conv_ws(const ConvArgs& a, int B, int precision, hipStream_t st) {
 namespace {
 bool ws_plan(const ConvArgs& a, int B, int precision, WsPlan& plan) {
   const bool x3 = precision == 0;  // fp32 storage: only where the caller allows it (ConvArgs.ws_f32) and the lo weights exist
-  static const int f32_env = getenv("VQVS_WS_F32") ? atoi(getenv("VQVS_WS_F32")) : 1;  // 0: the fp32 mode stays on conv_mfma_kernel (A/B)
-  if (!ws_enabled() || (x3 && (!a.ws_f32 || !f32_env || a.w_lo == nullptr || a.Cout % 64 != 0))) return 0;
+  if (!ws_available(precision) || (x3 && (!a.ws_f32 || a.w_lo == nullptr || a.Cout % 64 != 0))) return 0;
   const int es = x3 ? 4 : 2;
   if (a.Cout % 32 != 0 || a.out_f32 || a.epi_gelu || a.nbw || (a.out_rows != 0 && a.out_rows != a.Lout)) return 0;
   // rows per clip a source must have for a given resize (kernels.hpp RESIZE_*)
@@ -1426,7 +1433,11 @@ bool ws_plan(const ConvArgs& a, int B, int precision, WsPlan& plan) {
   // resident weights: one channel tile per launch and everything fits the CU's LDS
   static const int res_env = getenv("VQVS_WS_RES") ? atoi(getenv("VQVS_WS_RES")) : 1;  // 0: always stream the weights (A/B measurements)
   if (w.ss_bytes > 8192) return 0;  // (one 16-byte piece per producer thread)
-  w.ss_ring = (long long)w.ntx * w.nty * n >= 4 ? 2 : 4;
+  // (scale, shift) tables in LDS: the producers' load cursor runs up to four chunks ahead of the chunk being staged, and a table is
+  // written when the cursor ENTERS its clip -- so the ring must hold every clip between the staged chunk and the cursor:
+  // 2 clips when a clip takes at least four steps, 3 at two or three steps, 5 when a clip is a single step (32 x 3 -> 32, L <= 254)
+  const long long spc = (long long)w.ntx * w.nty * n;  // steps per clip
+  w.ss_ring = spc >= 4 ? 2 : (spc >= 2 ? 4 : 8);
   const int ss_total = w.ss_ring * w.ss_bytes;
   if (ws_fixed_lds(rows, CT, false, x3) + ss_total > ws_lds_cap(rows, x3)) return 0;
   // (avg-pooled launches stream their weights: resident weights + four loads per chunk do not fit 128 VGPRs without spills, and

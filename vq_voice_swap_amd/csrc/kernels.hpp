@@ -92,6 +92,8 @@ int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st);
 int launch_conv_ws(const ConvArgs& a, int B, int precision, hipStream_t st);
 // true when launch_conv_ws would take `a` AND build a.gn's (scale, shift) rows itself (then no gn_prepare launch is needed)
 bool ws_fuses_gn(const ConvArgs& a, int B, int precision);
+// false when the run-time switches (VQVS_WS=0, VQVS_WS_F32=0) keep this precision mode off conv_ws_kernel altogether
+bool ws_available(int precision);
 int conv_tile_rows(int dmax, int Cout, int precision, bool ws_ok = false);
 
 // ----------------------------------------------------------------------------------

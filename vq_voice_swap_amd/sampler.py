@@ -32,12 +32,21 @@ def _dist_info():
     return 0, 1
 
 
+# which branch the last gather_clips call took: "local" (no process group), "device_all_gather" (RCCL: device tensors) or
+# "host_all_gather" (gloo test runs) -- bench.py reports it, tests/test_rccl_gpu.py asserts it
+LAST_GATHER_PATH = "none"
+
+
 def gather_clips(local: torch.Tensor, n_total: int, T: int) -> Optional[torch.Tensor]:
-    """Gather variable-size shards [n_local,1,T] to rank 0 in global clip order (None elsewhere)."""
+    """Gather variable-size shards [n_local,1,T] to rank 0 in global clip order (None elsewhere).  With an initialised process
+    group the collective runs at EVERY world size, 1 included: a one-rank job under torchrun exercises the same RCCL calls as an
+    8-rank one (16 MB per rank: nothing next to the sampling time)."""
     import torch.distributed as dist
 
+    global LAST_GATHER_PATH
     rank, world = _dist_info()
-    if world == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        LAST_GATHER_PATH = "local"
         return local
     sizes = [shard_range(n_total, r, world) for r in range(world)]
     n_max = max(e - b for b, e in sizes)
@@ -48,12 +57,14 @@ def gather_clips(local: torch.Tensor, n_total: int, T: int) -> Optional[torch.Te
     # all_gather is the one collective every backend (RCCL, gloo) implements for equal-sized device tensors; the
     # payload (16 MB per rank at 64 clips) is negligible next to the sampling time, so rank 0 simply keeps its copy
     if pad.is_cuda and dist.get_backend() == "gloo":  # gloo gathers host tensors only (test runs; production is RCCL)
+        LAST_GATHER_PATH = "host_all_gather"
         host = pad.cpu()
         bufs = [torch.empty_like(host) for _ in range(world)]
         dist.all_gather(bufs, host)
         if rank != 0:
             return None
         return torch.cat([bufs[r][: e - b] for r, (b, e) in enumerate(sizes)], dim=0).to(pad.device)
+    LAST_GATHER_PATH = "device_all_gather" if pad.is_cuda else "host_all_gather"
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad)
     if rank != 0:

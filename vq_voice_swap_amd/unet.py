@@ -116,11 +116,18 @@ class _NativeModule(nn.Module):
             if h is not None:
                 h.close()
 
+    # an alternate-precision handle larger than this is closed when its override ends instead of waiting beside the module's own
+    # (weights + an activation arena sized for the largest batch and length it has seen: several GB at 64 clips of 4 s)
+    ALT_HANDLE_KEEP_BYTES = int(float(os.environ.get("VQVS_ALT_HANDLE_KEEP_GB", "2")) * 2 ** 30)
+
     @contextlib.contextmanager
     def precision_override(self, precision: str):
-        """Run in another precision mode for the duration of a call WITHOUT discarding the module's own device handle: the
-        override's handle is kept beside it (and rebuilt only when the weights change), the module's own mode, handle and arena
-        are back in place afterwards.  Used by VQVAE.decode_uncond_guidance, whose extrapolation needs the fp32 mode."""
+        """Run in another precision mode for the duration of a call WITHOUT discarding the module's own device handle: the module's
+        own mode, handle and arena are back in place afterwards.  Used by VQVAE.decode_uncond_guidance, whose extrapolation needs the
+        fp32 mode.  Memory: while the override is active BOTH handles exist (weights + arena each); afterwards the override's handle
+        is kept for the next call only if it is small (ALT_HANDLE_KEEP_BYTES, VQVS_ALT_HANDLE_KEEP_GB, default 2 GB) -- a large one
+        is closed, so repeated calls at full batch pay a rebuild (~0.3 s) instead of holding several GB; release_alt_handles()
+        drops a kept one explicitly.  Nested overrides are allowed; a handle is never orphaned."""
         if precision not in _native.PRECISIONS:
             raise ValueError(f"unknown precision {precision!r}; use 'fp32', 'fp16' or 'bf16'")
         if precision == self.precision:
@@ -133,8 +140,21 @@ class _NativeModule(nn.Module):
         try:
             yield self
         finally:
-            self.__dict__.setdefault("_alt_handles", {})[precision] = (self._handle, self._handle_key)
+            alt = self.__dict__.setdefault("_alt_handles", {})
+            stale = alt.pop(precision, (None, None))[0]  # (left by a nested override of the same precision: close, do not orphan)
+            if stale is not None and stale is not self._handle:
+                stale.close()
+            if self._handle is not None and self._handle.device_bytes() > self.ALT_HANDLE_KEEP_BYTES:
+                self._handle.close()
+            elif self._handle is not None:
+                alt[precision] = (self._handle, self._handle_key)
             self.precision, self._handle, self._handle_key = own
+
+    def release_alt_handles(self):
+        """Close the handles kept by precision_override (device memory back to the driver)."""
+        for h, _ in self.__dict__.pop("_alt_handles", {}).values():
+            if h is not None:
+                h.close()
 
     def _apply(self, fn, *a, **k):
         self.invalidate()
