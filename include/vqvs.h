@@ -20,8 +20,9 @@
  *     it, thread-local).  Nothing here falls back to a CPU path.
  *   - a handle is not thread-safe (one scratch arena); different handles are
  *     independent.  The handle-less entry points (vqvs_ddpm_step with CONSTRAIN,
- *     vqvs_vq_argmin) share one small scratch buffer per device (it only grows): issue them from
- *     one thread and one stream at a time.  One process per GPU.
+ *     vqvs_vq_argmin) keep one small scratch buffer per (device, stream): calls on
+ *     different streams never share it and may run concurrently; calls on one
+ *     stream are ordered by the stream.  One process per GPU.
  */
 #ifndef VQVS_H
 #define VQVS_H
@@ -97,8 +98,10 @@ int64_t vqvs_model_device_bytes(const vqvs_model* m);
  * eps = UNetPredictor.forward(x, ts, cond=, labels=)   reference unet.py:118-163
  *   d_x     [B,1,T] f32      d_ts [B] f32
  *   d_cond  [B,cond_channels,T1] f32 or NULL (must match cfg, unet.py:126-131); T1 = T/256 (cfg.reserved[3] = 0: cond from a
- *           UNet encoder) or (T/160 + 1 - 2)/2 + 1 = T/320 (reserved[3] = 1: cond from the MFCC encoder); it is added to the
- *           in_conv output through nearest-neighbour up-sampling to T, as F.interpolate does (unet.py:139)
+ *           UNet encoder), (T/160 + 1 - 2)/2 + 1 = T/320 (reserved[3] = 1: cond from the MFCC encoder), or ANY length L
+ *           (reserved[3] = 1000 + L: the handle then expects exactly L rows per clip, for every T); it is added to the
+ *           in_conv output through nearest-neighbour up-sampling to T, as F.interpolate(cond, T) does (unet.py:138-139),
+ *           with PyTorch's own source index min(floor(t * (float)L / T), L - 1)
  *   d_labels[B] int64 or NULL (must match cfg)
  *   d_out   [B,out_channels,T] f32 */
 int vqvs_unet_forward(vqvs_model* m, const float* d_x, const float* d_ts, const float* d_cond,

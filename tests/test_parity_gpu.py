@@ -95,6 +95,49 @@ def test_forward_is_deterministic_and_batch_independent(dev):
     assert torch.equal(a[1:2], c)
 
 
+def test_conditioning_of_any_length_vs_oracle(dev):
+    """The reference up-samples a conditioning sequence of ANY length to T (F.interpolate(cond, T), nearest; unet.py:138-139): lengths
+    that are neither T / 256 nor T / 320, shorter and longer than both, odd, one row, and longer than T / 2."""
+    model = det_model(VQVAE(base_channels=32, pred_name="unet", num_labels=4))
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    labels = torch.tensor([3, 1])
+    for T, Lc, seed in ((4096, 37, 1), (4096, 1, 2), (8192, 100, 3), (4096, 3000, 4), (4096, 16, 5), (8192, 513, 6)):
+        x, ts = seeded((2, 1, T), 70 + seed), torch.tensor([0.35, 0.8])
+        cond = seeded((2, 512, Lc), 80 + seed, 0.5)
+        want = ref_cpu.unet_predictor(sd, 32, x, ts, cond=cond, labels=labels)
+        for prec, tol in (("fp32", FP32_REL), ("fp16", FP16_REL)):
+            model.set_precision(prec)
+            got = model.predictor(x.to(dev), ts.to(dev), cond=cond.to(dev), labels=labels.to(dev)).cpu()
+            assert rel_rms(got, want) < tol, (prec, T, Lc, rel_rms(got, want))
+    model.set_precision("fp32")
+    with pytest.raises(ValueError, match="expected cond of shape"):
+        model.predictor(torch.zeros(2, 1, 4096, device=dev), torch.zeros(2, device=dev), cond=torch.zeros(2, 256, 16, device=dev), labels=labels.to(dev))
+
+
+def test_handle_less_entry_points_on_two_streams(dev):
+    """vqvs_ddpm_step(CONSTRAIN) and vqvs_vq_argmin keep their scratch per (device, stream): the same calls interleaved on two
+    streams give the results of running them one after the other."""
+    diff = Diffusion(make_schedule("exp"))
+    B, T = 6, 64000
+    xs = [seeded((B, 1, T), 500 + i).to(dev) for i in range(2)]
+    es = [seeded((B, 1, T), 510 + i).to(dev) for i in range(2)]
+    ns = [seeded((B, 1, T), 520 + i).to(dev) for i in range(2)]
+    ts = torch.full((B,), 0.6, device=dev)
+    model = det_model(VQVAE(base_channels=32, pred_name="unet", num_labels=2))
+    zs = [seeded((B, 512, 250), 530 + i).to(dev) for i in range(2)]
+    want = [(diff.ddpm_previous(xs[i], ts, 0.02, es[i], noise=ns[i], constrain=True), model.vq.encode(zs[i])) for i in range(2)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    got = [None, None]
+    for rep in range(8):
+        for i in range(2):
+            with torch.cuda.stream(streams[i]):
+                got[i] = (diff.ddpm_previous(xs[i], ts, 0.02, es[i], noise=ns[i], constrain=True), model.vq.encode(zs[i]))
+    torch.cuda.synchronize()
+    for i in range(2):
+        assert torch.equal(got[i][0], want[i][0]) and torch.equal(got[i][1], want[i][1]), i
+
+
 def test_bad_lengths_raise(dev):
     model = det_model(DiffusionModel("unet", 32))
     with pytest.raises(ValueError, match="multiple of the UNet downsample rate"):

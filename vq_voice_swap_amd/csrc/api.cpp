@@ -3,6 +3,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <utility>
 
 #include "net.hpp"
 #include "sampler_kernels.hpp"
@@ -12,29 +13,51 @@ static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
 
 // scratch of the handle-less entry points (DDPM step partial sums, VQ code norms, discarded logits): one buffer per
-// device, owned by that device.  It only ever grows; growing synchronises the OWNING device (which is the current one:
-// the map is keyed by hipGetDevice) before the old buffer is freed, so no queued kernel can still be using it.
+// (device, stream), so calls issued on different streams never share it -- work on ONE stream is ordered by the stream itself.
+// A buffer only ever grows; growing (or evicting the least recently used buffer once a device has more than MAX_STREAMS of
+// them) synchronises the OWNING device -- the current one: the map is keyed by hipGetDevice -- before the old buffer is freed,
+// so no queued kernel can still be using it.
 struct DeviceScratch {
   void* p = nullptr;
   size_t bytes = 0;
+  unsigned long long used = 0;
 };
-static std::map<int, DeviceScratch> g_scratch;
+static std::map<std::pair<int, void*>, DeviceScratch> g_scratch;
 static std::mutex g_scratch_mu;
-static int scratch_get(size_t bytes, void** out) {
+static unsigned long long g_scratch_tick = 0;
+static int scratch_get(size_t bytes, void* stream, void** out) {
+  constexpr size_t MIN_BYTES = (size_t)1 << 20;
+  constexpr size_t MAX_STREAMS = 32;
   std::lock_guard<std::mutex> lk(g_scratch_mu);
   int dev = 0;
   VQVS_HIP(hipGetDevice(&dev));
-  DeviceScratch& sc = g_scratch[dev];
+  const auto key = std::make_pair(dev, stream);
+  if (g_scratch.find(key) == g_scratch.end()) {
+    size_t n_dev = 0;
+    auto lru = g_scratch.end();
+    for (auto it = g_scratch.begin(); it != g_scratch.end(); ++it)
+      if (it->first.first == dev) {
+        ++n_dev;
+        if (lru == g_scratch.end() || it->second.used < lru->second.used) lru = it;
+      }
+    if (n_dev >= MAX_STREAMS) {  // (streams come and go: their buffers are reclaimed here, oldest first)
+      VQVS_HIP(hipDeviceSynchronize());
+      VQVS_HIP(hipFree(lru->second.p));
+      g_scratch.erase(lru);
+    }
+  }
+  DeviceScratch& sc = g_scratch[key];
   if (sc.p && sc.bytes < bytes) {
     VQVS_HIP(hipDeviceSynchronize());
     VQVS_HIP(hipFree(sc.p));
     sc = DeviceScratch{};
   }
   if (!sc.p) {
-    size_t n = bytes < (size_t)(4 << 20) ? (size_t)(4 << 20) : bytes;
+    size_t n = bytes < MIN_BYTES ? MIN_BYTES : bytes;
     VQVS_HIP(hipMalloc(&sc.p, n));
     sc.bytes = n;
   }
+  sc.used = ++g_scratch_tick;
   *out = sc.p;
   return 0;
 }
@@ -208,7 +231,7 @@ int vqvs_classifier_guidance(vqvs_model* m, const float* d_x, const float* d_ts,
   float* logits = d_logits;
   if (!logits) {
     void* scratch = nullptr;
-    if (int e = scratch_get((size_t)B * m->cfg.num_labels * 4, &scratch)) return e;
+    if (int e = scratch_get((size_t)B * m->cfg.num_labels * 4, stream, &scratch)) return e;
     logits = reinterpret_cast<float*>(scratch);
   }
   RunCtx c;
@@ -265,7 +288,7 @@ int vqvs_ddpm_step(const float* d_x_t, const float* d_eps, const float* d_noise,
   if (B < 1 || T < 1) VQVS_FAIL(VQVS_ERR_ARG, "bad shape B=%d T=%d", B, T);
   void* scratch = nullptr;
   if (flags & VQVS_DDPM_CONSTRAIN)
-    if (int e = scratch_get((size_t)ddpm_scratch_doubles(B, T) * 8, &scratch)) return e;
+    if (int e = scratch_get((size_t)ddpm_scratch_doubles(B, T) * 8, stream, &scratch)) return e;
   return run_ddpm_step(d_x_t, d_eps, d_noise, d_alpha_t, d_alpha_prev, d_x_prev, reinterpret_cast<double*>(scratch), B, T, flags,
                        noise_scale, seed, clip_offset, step_index, reinterpret_cast<hipStream_t>(stream));
 }
@@ -292,7 +315,7 @@ int vqvs_vq_argmin(const float* d_z, const float* d_dict, int64_t* d_idx, int B,
   if (B < 1 || Cd < 1 || T1 < 1 || K < 1) VQVS_FAIL(VQVS_ERR_ARG, "bad shape");
   if (Cd % 4) VQVS_FAIL(VQVS_ERR_ARG, "Cd must be a multiple of 4 (got %d)", Cd);
   void* scratch = nullptr;
-  if (int e = scratch_get((size_t)K * 4, &scratch)) return e;
+  if (int e = scratch_get((size_t)K * 4, stream, &scratch)) return e;
   return run_vq_argmin(d_z, d_dict, reinterpret_cast<float*>(scratch), d_idx, B, Cd, T1, K, reinterpret_cast<hipStream_t>(stream));
 }
 

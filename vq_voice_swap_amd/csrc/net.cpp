@@ -188,11 +188,15 @@ constexpr int LEN_FRAMES = 100;   // T / hop + 1                      (torch.stf
 constexpr int LEN_FRAMES_PAD = 101;  // frames rounded up to even: allocation of the tensor the stride-2 convolution reads
 constexpr int LEN_PAIRS = 102;    // LEN_FRAMES_PAD / 2: rows of that tensor viewed as [pairs][2 * channels]
 constexpr int LEN_HALF = 103;     // (frames + 2 - 4) / 2 + 1: output length of Conv1d(k = 4, stride = 2, padding = 1)
+constexpr int LEN_ABS = 1000;     // lshift >= LEN_ABS: a fixed number of rows, lshift - LEN_ABS, whatever the base length (a conditioning
+                                  // sequence of arbitrary length: the reference up-samples ANY length to T, unet.py:138-139)
 double lscale(int lshift) {
+  if (lshift >= LEN_ABS) return 0.0;  // (not proportional to the base length: left out of the per-unit-length accounting)
   if (lshift >= LEN_FRAMES) return (lshift == LEN_PAIRS || lshift == LEN_HALF ? 0.5 : 1.0) / MFCC_HOP;
   return lshift >= 0 ? 1.0 / (double)(1 << lshift) : (double)(1 << -lshift);
 }
 int shiftL(int L, int lshift) {
+  if (lshift >= LEN_ABS) return lshift - LEN_ABS;
   if (lshift >= LEN_FRAMES) {
     const int frames = L / MFCC_HOP + 1;
     if (lshift == LEN_FRAMES) return frames;
@@ -975,7 +979,8 @@ static int check_cfg(const vqvs_cfg& c) {
   if (c.kind == VQVS_KIND_PREDICTOR) {
     if (c.out_channels != 1 && (c.out_channels % 32)) VQVS_FAIL(VQVS_ERR_ARG, "out_channels must be 1 or a multiple of 32");
     if (c.cond_channels % 32) VQVS_FAIL(VQVS_ERR_ARG, "cond_channels must be a multiple of 32");
-    if (c.reserved[3] != 0 && c.reserved[3] != 1) VQVS_FAIL(VQVS_ERR_ARG, "cond length code (reserved[3]) must be 0 (T/256) or 1 (T/320)");
+    if (c.reserved[3] != 0 && c.reserved[3] != 1 && (c.reserved[3] <= LEN_ABS || c.reserved[3] > LEN_ABS + (1 << 20)))
+      VQVS_FAIL(VQVS_ERR_ARG, "cond length code (reserved[3]) must be 0 (T/256), 1 (T/320) or 1000 + rows per clip (1 .. 2^20)");
   } else if (c.kind == VQVS_KIND_ENCPRED) {
     if (c.out_channels % 32 || c.out_channels < 32 || c.out_channels > 256) VQVS_FAIL(VQVS_ERR_ARG, "bottleneck_dim must be a multiple of 32 in 32..256");
     if (c.cond_channels) VQVS_FAIL(VQVS_ERR_ARG, "the encoder predictor's UNet is unconditional");
@@ -1106,7 +1111,8 @@ int build_model(vqvs_model* m, const float* const* hp) {
     const bool has_cond = c.cond_channels > 0;
     if (has_cond) {
       // conditioning rows per clip: T / 256 behind a UNet encoder, (T / 160 + 1 - 2) / 2 + 1 = T / 320 behind the MFCC encoder
-      const int cond_ls = c.reserved[3] == 1 ? LEN_HALF : 8;
+      // or, reserved[3] = 1000 + rows, exactly that many rows for any T (nearest up-sampling to T with PyTorch's index formula, in_conv)
+      const int cond_ls = c.reserved[3] >= LEN_ABS ? c.reserved[3] : (c.reserved[3] == 1 ? LEN_HALF : 8);
       TensorH ct = b.new_tensor(c.cond_channels, cond_ls, false, false);
       const int CC = c.cond_channels;
       m->meta.push_back({"nct_to_ntc", "", 0, 0, 0});

@@ -276,7 +276,7 @@ class UNetPredictor(_NativeModule):
         self.in_channels = in_channels
         self.out_channels = out_channels
         self.dropout = dropout
-        self._cond_code = 0  # conditioning rows per clip: 0 = T / 256 (UNet encoder), 1 = T / 320 (ConvMFCCEncoder)
+        self._cond_code = 0  # conditioning rows per clip: 0 = T / 256 (UNet encoder), 1 = T / 320 (ConvMFCCEncoder), 1000 + L = exactly L rows
 
         C = base_channels
         E = 4 * C
@@ -342,13 +342,15 @@ class UNetPredictor(_NativeModule):
             raise ValueError(f"expected ts of shape [{B}], got {tuple(ts.shape)}")
         if cond is not None:
             cond = cond.detach().to(torch.float32).contiguous()
-            # the reference up-samples ANY cond length to T (F.interpolate, unet.py:139); the library knows the two lengths
-            # its encoders produce: T / 256 (UNetEncoder) and (T / 160 + 1 - 2) / 2 + 1 = T / 320 (ConvMFCCEncoder)
-            lens = {T // 256: 0, (T // 160 + 1 - 2) // 2 + 1: 1}
-            if tuple(cond.shape[:2]) != (B, self.cond_channels) or cond.shape[2] not in lens:
-                raise ValueError(f"expected cond of shape {(B, self.cond_channels)} x {sorted(lens)}, got {tuple(cond.shape)}")
-            if lens[cond.shape[2]] != self._cond_code:
-                self._cond_code = lens[cond.shape[2]]
+            # the reference up-samples ANY cond length to T (F.interpolate(cond, T), nearest; unet.py:138-139), and so does in_conv.
+            # The two lengths the encoders produce -- T / 256 (UNetEncoder) and (T / 160 + 1 - 2) / 2 + 1 = T / 320 (ConvMFCCEncoder)
+            # -- are length CODES of the handle (valid for every T); any other length builds a handle for exactly that many rows.
+            if tuple(cond.shape[:2]) != (B, self.cond_channels) or cond.shape[2] < 1:
+                raise ValueError(f"expected cond of shape {(B, self.cond_channels)} x L, got {tuple(cond.shape)}")
+            lens = {(T // 160 + 1 - 2) // 2 + 1: 1, T // 256: 0}
+            code = lens.get(cond.shape[2], 1000 + cond.shape[2])
+            if code != self._cond_code:
+                self._cond_code = code
                 self.invalidate()
         if labels is not None:
             labels = labels.detach().to(device=x.device, dtype=torch.int64).contiguous()
