@@ -114,6 +114,24 @@ def test_conditioning_of_any_length_vs_oracle(dev):
         model.predictor(torch.zeros(2, 1, 4096, device=dev), torch.zeros(2, device=dev), cond=torch.zeros(2, 256, 16, device=dev), labels=labels.to(dev))
 
 
+def test_whole_clip_tiles_for_wide_dilations_vs_oracle(dev):
+    """The middle blocks' shapes (unet.py:21, 78-88: dilation 4 .. 32 at 250 rows, 256 / 512 channels): a clip of at most 255 rows is
+    one zero-padded tile of conv_ws_kernel whatever the dilation (template flag ZP) -- every dilation, clip lengths around the limits
+    (255 = last length covered, 256 = back on two tiles, shorter than the dilation's reach, odd), against the oracle."""
+    cases = [(256, 4, 250, 3), (256, 8, 250, 2), (256, 16, 255, 2), (256, 32, 250, 3), (512, 32, 250, 2), (512, 4, 131, 2),
+             (256, 32, 37, 2), (256, 16, 256, 2), (256, 3, 253, 2)]
+    for i, (C, dil, L, B) in enumerate(cases):
+        m = ResBlockModule(C, 128, None, 1.0, dil)
+        det_init_((f"zp{i}." + k, v) for k, v in m.block.state_dict().items())
+        x, e = seeded((B, C, L), 600 + i), seeded((B, 128), 650 + i)
+        sd = {"b." + k: v.detach() for k, v in m.block.state_dict().items()}
+        want = ref_cpu.res_block(x, sd, "b", dict(cin=C, cout=C, scale=1.0, dil=dil), e)
+        for prec, tol in (("fp32", 2e-4), ("fp16", 4e-3), ("bf16", BF16_REL)):
+            m.set_precision(prec)
+            got = m(x.to(dev), e.to(dev)).cpu()
+            assert rel_rms(got, want) < tol, (prec, C, dil, L, rel_rms(got, want))
+
+
 def test_handle_less_entry_points_on_two_streams(dev):
     """vqvs_ddpm_step(CONSTRAIN) and vqvs_vq_argmin keep their scratch per (device, stream): the same calls interleaved on two
     streams give the results of running them one after the other."""

@@ -173,6 +173,7 @@ struct WsArgs {
   int ss_bytes;    // bytes of one clip's (scale, shift) table (all prologue segments), ss_ring copies of it live in LDS
   int ss_ring;     // 2, 4 or 8 (power of two): clips whose chunks can be in flight at once
   int rev;         // 1: the launch walks its tiles from the last to the first (ConvArgs.rev)
+  int zp;          // 1: whole-clip tiles (template flag ZP): a clip of at most 255 rows is ONE tile whatever the dilation
 };
 static_assert(offsetof(WsArgs, gn) == 0, "gn_table reads WsGn through the kernarg segment pointer: it must stay the first member");
 #define WS_SEGF(s, f) ((s) == 0 ? a.seg[0].f : ((s) == 1 ? a.seg[1].f : ((s) == 2 ? a.seg[2].f : a.seg[3].f)))
@@ -213,7 +214,13 @@ __device__ unsigned long long g_ws_timing[32];
 // and split ONCE per 128 output channels instead of once per 64 (a producer thread then stages one row of a chunk, not two).
 template <typename T, int ROWS>
 constexpr int ws_threads() { return sizeof(T) == 4 ? 1024 : ROWS * 4; }
-template <typename T, int ROWS, int CT, bool RES, bool AVG>
+// ZP ("zero padded"): the whole clip is ONE tile.  A tile normally stages 256 rows of which 256 - 2 * dilation are output rows, so the
+// middle blocks' dilations 4 .. 32 (unet.py:21) turn a 250-row clip into TWO tiles of twice the work.  Where the clip has at most 255
+// rows, every halo row is the convolution's zero padding: LDS row r then holds time r for every segment, rows from Lout on are staged
+// as zeros anyway, and a tap whose row falls outside [0, 256) reads row 255 -- a row of zeros -- instead (per-lane A addresses for
+// both 32-row blocks, rebuilt only when the dilation changes).  One tile per (clip, channel tile): the statistics of the tiles the
+// static schedule expects beyond the first are written as zeros.
+template <typename T, int ROWS, int CT, bool RES, bool AVG, bool ZP = false>
 __global__ __launch_bounds__((ws_threads<T, ROWS>())) void conv_ws_kernel(const WsArgs a) {
   constexpr bool X3 = sizeof(T) == 4;     // fp32 storage: hi / lo bf16 planes of activations and weights, three MFMAs per product
   constexpr bool TALL = X3 && ROWS == 128;
@@ -233,6 +240,7 @@ __global__ __launch_bounds__((ws_threads<T, ROWS>())) void conv_ws_kernel(const 
   static_assert(!X3 || (CT == 64 && ROWS == 256) || (CT == 128 && ROWS == 128), "fp32 storage: 256 x 64 or 128 x 128 tiles");
   static_assert(PR == 1 || PR == 2, "producer rows per chunk");
   static_assert(!TALL || !RES, "the 128 x 128 fp32 tile streams its weights (two planes of 3 x 128 x 64 B per chunk)");
+  static_assert(!ZP || (!X3 && !RES && !AVG && ROWS == 256 && CT >= 64), "whole-clip tiles: 2-byte storage, streaming 256-row tiles of 64 / 128 channels");
   constexpr int ACT_BYTES = ROWS * 64;    // staged rows x 32 channels (one bf16 / fp16 plane)
   constexpr int W_BYTES = 3 * CT * 64;    // ... of weights
   constexpr int ACT2 = (X3 ? 2 : 1) * ACT_BYTES, W2 = (X3 ? 2 : 1) * W_BYTES;  // [hi plane][lo plane]
@@ -377,7 +385,8 @@ __global__ __launch_bounds__((ws_threads<T, ROWS>())) void conv_ws_kernel(const 
       cur.rs[1] = (int)((unsigned)(clip >> 32) & 0xffffu);
       cur.rs[2] = (VQVS_WS_EXP & 2048) ? 0x7fffffff : f.clip_bytes;
       cur.rs[3] = 0x00020000;
-      const int tm0 = lt.tx * a.TTO - f.dil + r0, tm1 = tm0 + HR;  // time of this thread's two rows
+      const int sdil = ZP ? 0 : f.dil;  // (ZP: LDS row r holds time r)
+      const int tm0 = lt.tx * a.TTO - sdil + r0, tm1 = tm0 + HR;  // time of this thread's two rows
       const int sr0 = f.rsz == RESIZE_UP2 ? (tm0 >> 1) : (f.rsz == RESIZE_AVG2 ? 2 * tm0 : tm0);  // (first) source row of row 0
       cur.off0 = (sr0 * f.Csrc + f.c0 + (f.ntaps == 0 ? lt.ty * CT : 0) + oct * 8) * ES;
       cur.off1 = cur.off0 + (f.rsz == RESIZE_UP2 ? HR : (f.rsz == RESIZE_AVG2 ? 4 * HR : 2 * HR)) * f.Csrc * (ES / 2);
@@ -390,7 +399,7 @@ __global__ __launch_bounds__((ws_threads<T, ROWS>())) void conv_ws_kernel(const 
       cur.ssaddr = SS_OFF + (lt.b & (a.ss_ring - 1)) * a.ss_bytes + f.ss_lds + oct * 64;
       cur_xf = f.ss != nullptr ? 1 : 0;
       cur_valid = ((tm0 >= 0 && tm0 < L) ? 2u : 0u) | ((tm1 >= 0 && tm1 < L) ? 4u : 0u);
-      cur_edge = (lt.tx * a.TTO - f.dil < 0 || lt.tx * a.TTO - f.dil + ROWS > L) ? 1 : 0;
+      cur_edge = (lt.tx * a.TTO - sdil < 0 || lt.tx * a.TTO - sdil + ROWS > L) ? 1 : 0;
       lnch = f.nch;
       nx = fetch(lseg + 1 == a.nseg ? 0 : lseg + 1);
     };
@@ -785,6 +794,8 @@ __global__ __launch_bounds__((ws_threads<T, ROWS>())) void conv_ws_kernel(const 
         }
         float2* o = reinterpret_cast<float2*>(a.stats) + ((size_t)pt_.b * a.ntiles_stat + pt_.tx) * a.Cout + co0 + ltid;
         *o = float2{t1, t2};
+        if constexpr (ZP)  // (the clip's only tile: the further statistics tiles the schedule's GroupNorm sums hold nothing)
+          for (int t = 1; t < a.ntiles_stat; ++t) o[(size_t)t * a.Cout] = float2{0.f, 0.f};
       }
       if constexpr (WPE || X3) return;  // (the rows left with their wave, at the tile's last step)
       // out-tile -> global: a thread takes 8 channels of a row pair (2 x 16 B of LDS), separates the two rows (lo / hi halves of
@@ -866,8 +877,22 @@ __global__ __launch_bounds__((ws_threads<T, ROWS>())) void conv_ws_kernel(const 
     dma(dw.ntaps, d_woff, nt_, 0);
     int ntaps = dw.ntaps, d = dw.dil, wb = wlds(0);  // current chunk
     dma_advance();
+    // the first tile's bias: requested here, behind the weights, so that its latency passes behind the tables and the first barrier
+    // (it used to be loaded -- and waited for -- at the first step, ~1.5 us on the critical path of a one-tile workgroup)
+    float bj[WN], bjn[WN];
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt) bjn[nt] = bj[nt] = a.bias[first.ty * CT + wc * (WN * 32) + nt * 32 + l31];
+    int bias_ty = first.ty;
+    // Tables only for the clips this workgroup reaches: [first.b, last_b] in walk order.  At the deep levels a workgroup owns ONE tile
+    // (64 clips x 4 channel tiles = 256 tiles), and the table of the clip `ss_ring / 2` on -- two dependent round trips to global
+    // memory plus fp64 arithmetic, ~4-5 us at the first step -- was built for a clip the workgroup never touches.
+    const int last_b = (a.rev ? a.ntiles - te : te - 1) / (a.ntx * a.nty);
+    auto reaches = [&](int c) { return a.rev ? (c >= last_b && c <= first.b) : (c >= first.b && c <= last_b); };
     if (a.gn.nsrc > 0)
-      for (int i = 0; i < (a.ss_ring >> 1); ++i) gn_table(first.b + (a.rev ? -i : i));
+      for (int i = 0; i < (a.ss_ring >> 1); ++i) {
+        const int c = first.b + (a.rev ? -i : i);
+        if (reaches(c)) gn_table(c);
+      }
 #ifdef VQVS_TIMING
     const unsigned long long t_su1 = __builtin_amdgcn_s_memtime();  // (startup marks: requests out, first tables built)
 #endif
@@ -876,12 +901,12 @@ __global__ __launch_bounds__((ws_threads<T, ROWS>())) void conv_ws_kernel(const 
 #ifdef VQVS_TIMING
     const unsigned long long t_su2 = __builtin_amdgcn_s_memtime();  // (first barrier passed)
 #endif
-    float bj[WN];
-    int bias_ty = -1;
     // (k-step 1 = the same address with bit 5 flipped: the swizzle XORs the 16-byte column index.  The WPE instantiation has no
     //  registers to spare and flips the bit at every use; the others keep both addresses.)
-    constexpr int NKS = WPE ? 1 : 2;
+    constexpr int NKS = (WPE || ZP) ? 1 : 2;
     int aoff[3][NKS], aoff_d = -1;
+    int aoff1[ZP ? 3 : 1];  // ZP: the second 32-row block's own addresses (its rows leave [0, 256) at other lanes than the first's)
+    (void)aoff1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // first chunk's (or all resident) weights have landed
 #ifdef VQVS_TIMING
     const unsigned long long t_su3 = __builtin_amdgcn_s_memtime();  // (weights landed)
@@ -899,16 +924,22 @@ __global__ __launch_bounds__((ws_threads<T, ROWS>())) void conv_ws_kernel(const 
       if (cci == 0) {  // first chunk of a tile
         if (gn_ahead != 0 && ct.b != gn_clip) {  // ... of a clip: the table of the clip `ss_ring / 2` clips on (its slot is free by now)
           gn_clip = ct.b;
-          gn_table(ct.b + gn_ahead);
+          if (reaches(ct.b + gn_ahead)) gn_table(ct.b + gn_ahead);
         }
         if ((n == 1 || (VQVS_WS_EXP & 256)) && pending) {  // (one-chunk tiles: the previous tile leaves here, from the other buffer)
           store_tile();
           pending = false;
         }
-        if (ct.ty != bias_ty) {  // (one channel tile per launch at Cout <= 128: loaded once)
+        if (ct.ty != bias_ty) {  // (one channel tile per launch at Cout <= 128: loaded once, at start-up)
           bias_ty = ct.ty;
 #pragma unroll
-          for (int nt = 0; nt < WN; ++nt) bj[nt] = a.bias[ct.ty * CT + wc * (WN * 32) + nt * 32 + l31];
+          for (int nt = 0; nt < WN; ++nt) bj[nt] = bjn[nt];  // requested a tile ago
+        }
+        if (a.nty > 1) {  // several channel tiles (channel tile fastest): the NEXT tile's bias is requested now and has a whole tile to arrive
+          TileCo nxt = ct;
+          next_tile(nxt);
+#pragma unroll
+          for (int nt = 0; nt < WN; ++nt) bjn[nt] = a.bias[nxt.ty * CT + wc * (WN * 32) + nt * 32 + l31];
         }
         // (the bias as the C operand of the tile's first MFMAs, from a 16-register tile, instead of these v_mov: measured +0.4 %
         //  convolution time -- the second code copy of the first tap costs more than the moves)
@@ -961,9 +992,19 @@ __global__ __launch_bounds__((ws_threads<T, ROWS>())) void conv_ws_kernel(const 
           aoff_d = d;
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
+            if constexpr (ZP) {
+              // tap k of output row r reads time r + (k - 1) d (1-tap and identity chunks: d = 0); outside the staged 256 rows lies
+              // only zero padding (host: Lout <= 255), and row 255 is a row of zeros
+              int row = wt * RW + l31 + (k - 1) * d, row1 = row + 32;
+              row = (unsigned)row < 256u ? row : 255;
+              row1 = (unsigned)row1 < 256u ? row1 : 255;
+              aoff[k][0] = row * 64 + ((hh ^ ((row >> 2) & 3)) << 4);
+              aoff1[k] = row1 * 64 + ((hh ^ ((row1 >> 2) & 3)) << 4);
+            } else {
             const int row = wt * RW + l31 + k * d;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) aoff[k][ks] = (row * 64 + ((hh ^ ((row >> 2) & 3)) << 4)) ^ (ks * 32);
+            }
           }
         }
         // LDS address of this lane's B fragments, per MFMA tile and k-step: the chunk's weights, or for an identity chunk j (= wb)
@@ -980,7 +1021,8 @@ __global__ __launch_bounds__((ws_threads<T, ROWS>())) void conv_ws_kernel(const 
             const int ao = NKS == 2 ? aoff[k][ks % NKS] : (aoff[k][0] ^ (ks * 32));
             const V8 a0 = *reinterpret_cast<const V8*>(sb + ao);
             V8 a1 = a0;
-            if constexpr (MT == 2) a1 = *reinterpret_cast<const V8*>(sb + ao + 32 * 64);
+            if constexpr (ZP) a1 = *reinterpret_cast<const V8*>(sb + (aoff1[k] ^ (ks * 32)));
+            else if constexpr (MT == 2) a1 = *reinterpret_cast<const V8*>(sb + ao + 32 * 64);
 #pragma unroll
             for (int nt = 0; nt < WN; ++nt) {
               const V8 bf = *reinterpret_cast<const V8*>(smem + (NKS == 2 ? bad[nt][ks % NKS] : (bad[nt][0] ^ (ks * 32))) + k * (CT * 64));
@@ -1253,21 +1295,21 @@ constexpr int WS_LDS_MAX = 160 * 1024;
 // LDS one workgroup may use: two workgroups of the 128-row geometry share a CU
 constexpr int ws_lds_cap(int rows, bool x3 = false) { return (rows == 256 || x3) ? WS_LDS_MAX : WS_LDS_MAX / 2; }
 
-template <typename T, int ROWS, int CT, bool RES, bool AVG>
+template <typename T, int ROWS, int CT, bool RES, bool AVG, bool ZP = false>
 int ws_launch(const WsArgs& w, hipStream_t st) {
   constexpr bool X3 = sizeof(T) == 4;
   const int lds = ws_fixed_lds(ROWS, CT, RES, X3) + (RES ? (X3 ? 2 : 1) * w.wres_bytes : 0) + w.ss_ring * w.ss_bytes;
   static std::atomic<bool> attr_done[WS_MAX_DEV];  // (per instantiation and device; setting it twice from two threads is harmless)
   const int dev = ws_cur_dev();
   if (!attr_done[dev].load(std::memory_order_acquire)) {
-    VQVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<T, ROWS, CT, RES, AVG>), hipFuncAttributeMaxDynamicSharedMemorySize, ws_lds_cap(ROWS, X3)));
+    VQVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<T, ROWS, CT, RES, AVG, ZP>), hipFuncAttributeMaxDynamicSharedMemorySize, ws_lds_cap(ROWS, X3)));
     attr_done[dev].store(true, std::memory_order_release);
   }
   static const int grid_env = getenv("VQVS_WS_GRID") ? atoi(getenv("VQVS_WS_GRID")) : 0;  // (A/B measurements: workgroups per launch)
   constexpr int NT = ws_threads<T, ROWS>();
   const int nwg = (grid_env > 0 ? grid_env : ws_num_cus()) * (1024 / NT);  // persistent workgroups: one (two) per CU
   const int grid = w.ntiles < nwg ? w.ntiles : nwg;
-  hipLaunchKernelGGL((conv_ws_kernel<T, ROWS, CT, RES, AVG>), dim3(grid), dim3(NT), lds, st, w);
+  hipLaunchKernelGGL((conv_ws_kernel<T, ROWS, CT, RES, AVG, ZP>), dim3(grid), dim3(NT), lds, st, w);
   VQVS_HIP(hipGetLastError());
   return 0;
 }
@@ -1285,6 +1327,10 @@ int ws_launch_f32(const WsArgs& w, int rows, bool res, hipStream_t st) {  // fp3
 }
 template <typename T>
 int ws_launch_t(const WsArgs& w, int rows, int CT, bool res, bool avg, hipStream_t st) {
+  if (w.zp) {
+    if (rows != 256 || res || avg || CT < 64) return -1;
+    return CT == 128 ? ws_launch<T, 256, 128, false, false, true>(w, st) : ws_launch<T, 256, 64, false, false, true>(w, st);
+  }
   if (rows == 128) {  // (two workgroups per CU; 32-channel tiles only come in the 256-row geometry)
     if (CT == 128) return ws_launch_f<T, 128, 128>(w, res, avg, st);
     if (CT == 64) return ws_launch_f<T, 128, 64>(w, res, avg, st);
@@ -1360,7 +1406,17 @@ bool ws_plan(const ConvArgs& a, int B, int precision, WsPlan& plan) {
     if (a.seg[s].ntaps == 3 && a.seg[s].dil > dmax0) dmax0 = a.seg[s].dil;
   // fp32 storage: the schedule builder asks for the 128-row x 128-channel tile through tile_rows (conv_tile_rows)
   const bool tall = x3 && a.Cout % 128 == 0 && a.tile_rows > 0 && a.tile_rows == 128 - 2 * dmax0;
-  const int CT = x3 ? (tall ? 128 : 64) : (a.Cout % 128 == 0 ? 128 : (a.Cout % 64 == 0 ? 64 : 32));
+  int CT = x3 ? (tall ? 128 : 64) : (a.Cout % 128 == 0 ? 128 : (a.Cout % 64 == 0 ? 64 : 32));
+  // Short launches (the deep levels at half a node's batch, 32 clips: 128 tiles of 128 channels for 256 CUs): when 128-channel tiles
+  // would leave half of the chip idle, 64-channel tiles put a tile on every CU -- half the MFMAs per step for the same number of
+  // dependent steps.  Bitwise the same results: a tile's width enters neither its elements' sums nor the order of its statistics.
+  static const int narrow_env = getenv("VQVS_WS_NARROW") ? atoi(getenv("VQVS_WS_NARROW")) : 1;  // 0: off (A/B measurements)
+  // (only from 256 output channels: a 128-channel launch may keep its weights resident, and that form's wave-private epilogue sums
+  //  the tile statistics in another order than the out-tile epilogue -- the batch size must not change a clip's bits)
+  if (narrow_env && !x3 && CT == 128 && a.Cout >= 256 && a.tile_rows > 0) {
+    const long long rt = a.Lout <= 255 ? 1 : (a.Lout + a.tile_rows - 1) / a.tile_rows;  // (a clip of <= 255 rows is one tile: ZP, below)
+    if (rt * (a.Cout / 128) * B * 2 <= ws_num_cus()) CT = 64;
+  }
   plan.w = WsArgs{};
   WsArgs& w = plan.w;
   int dmax = 0, n = 0;
@@ -1425,6 +1481,13 @@ bool ws_plan(const ConvArgs& a, int B, int precision, WsPlan& plan) {
   w.TTO = a.tile_rows;
   w.ntx = (a.Lout + a.tile_rows - 1) / a.tile_rows;
   w.nty = a.Cout / CT;
+  // whole-clip tiles (template flag ZP): the clip fits one staged window of zero-padded rows although its dilation would split it
+  static const int zp_env = getenv("VQVS_WS_ZP") ? atoi(getenv("VQVS_WS_ZP")) : 1;  // 0: off (A/B measurements)
+  if (zp_env && !x3 && CT >= 64 && !avg && rows == 256 && a.Lout <= 255 && w.ntx > 1 && w.nty > 1) {  // (nty > 1: never a resident-weights launch)
+    w.zp = 1;
+    w.TTO = 256;
+    w.ntx = 1;
+  }
   w.ntiles = w.ntx * w.nty * B;
   w.ntiles_stat = a.ntiles;
   static const int rev_env = getenv("VQVS_WS_REV") ? atoi(getenv("VQVS_WS_REV")) : 1;  // 0: every launch walks forward (A/B measurements)
