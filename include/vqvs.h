@@ -69,12 +69,25 @@ typedef struct vqvs_cfg {
   int32_t num_labels;    /* 0 = no class embedding (unet.py:44-45) */
   int32_t precision;     /* VQVS_PREC_* */
   int32_t max_batch;     /* scratch arena is sized for this many clips ... */
-  int32_t max_T;         /* ... of this many samples (multiple of 256 for UNets) */
+  int32_t max_T;         /* ... of this many samples (a multiple of the UNet's downsample rate: 256 for the default topology) */
   int32_t debug_taps;    /* 1 = keep every block output resident for vqvs_debug_read_tap */
   /* VQVS_KIND_RESBLOCK only: */
   int32_t rb_cin, rb_cout, rb_resize /*0 none, 1 avg-pool/2, 2 nearest x2*/, rb_dilation, rb_emb_channels /*0 = no FiLM*/;
   int32_t reserved[5];
+  /* Topology of VQVS_KIND_PREDICTOR / VQVS_KIND_ENCODER (reference UNetPredictor.__init__ unet.py:17-30, UNetEncoder.__init__
+   * unet.py:188-196).  topology_set = 0: the reference's defaults -- channel_mult (1,1,2,2,2,4,4,8,8), depth_mult 2,
+   * middle_dilations (4,8,16,32) / out_dilations () -- and the fields below are ignored.  topology_set = 1: they describe the
+   * network: n_levels = len(channel_mult) in 1..VQVS_MAX_LEVELS, every channel_mult[i] * base_channels a multiple of 32 and at most
+   * 1024; depth_mult in 1..8; n_dilations = len(middle_dilations) (predictor) or len(out_dilations) (encoder), 0 allowed, each
+   * dilation in 1..32.  T must be a multiple of 2^(n_levels - 1). */
+  int32_t topology_set;
+  int32_t n_levels;
+  int32_t channel_mult[12];
+  int32_t depth_mult;
+  int32_t n_dilations;
+  int32_t dilations[12];
 } vqvs_cfg;
+#define VQVS_MAX_LEVELS 12
 
 /* ---- parameters -----------------------------------------------------------
  * The library owns the topology.  It enumerates the parameters it needs under

@@ -573,6 +573,55 @@ def gen_vqvae64_decode50():
          noise_checksum=np.array([n.double().sum().item() for n in noises]))
 
 
+# ---------------------------------------------------------------- F14: the reference's OPEN topology (unet.py:17-30, 188-196)
+def gen_custom_topologies():
+    """UNetPredictor / UNetEncoder built with channel_mult / depth_mult / middle_dilations / out_dilations other than the defaults,
+    by the reference's own constructors: forward outputs on seeded inputs."""
+    from vq_voice_swap.models.unet import UNetEncoder, UNetPredictor  # reference
+
+    out = {}
+    preds = [
+        ("p_a", dict(channel_mult=(1, 2, 2, 4), middle_dilations=(1, 6), depth_mult=1), dict(num_labels=3), 2048),
+        ("p_b", dict(channel_mult=(1, 1, 2), middle_dilations=(), depth_mult=3), {}, 1024),
+        ("p_c", dict(channel_mult=(1, 4, 8, 8, 16), middle_dilations=(2, 32, 5), depth_mult=2), dict(cond_channels=64), 4096),  # (channel_mult[0] must be 1: the reference normalises its output with base_channels, unet.py:113)
+    ]
+    for tag, topo, extra, T in preds:
+        m = UNetPredictor(32, **topo, **extra)
+        det_init_(("predictor." + tag + "." + k, v) for k, v in m.state_dict().items())
+        m.eval()
+        sd = {"predictor." + k: v.detach().clone() for k, v in m.state_dict().items()}
+        x, ts = seeded((2, 1, T), 700 + len(out)), torch.tensor([0.4, 0.85])
+        kw = {}
+        if "num_labels" in extra:
+            kw["labels"] = torch.tensor([2, 0])
+        if "cond_channels" in extra:
+            kw["cond"] = seeded((2, 64, 29), 750, 0.5)  # (a conditioning length that is no fixed fraction of T)
+        with torch.no_grad():
+            eps = m(x, ts, **kw)
+        check("custom predictor " + tag, eps, ref_cpu.unet_predictor(sd, 32, x, ts, topology=topo, **kw))
+        out[tag + ".x"], out[tag + ".ts"], out[tag + ".eps"] = x, ts, eps
+        for k, v in kw.items():
+            out[tag + "." + k] = v
+        print(f"  {tag}: {topo} eps rms={eps.pow(2).mean().sqrt().item():.4f}, {sum(p.numel() for p in m.parameters()) / 1e6:.2f} M parameters")
+    encs = [
+        ("e_a", dict(channel_mult=(1, 2, 4), out_dilations=(2, 8), depth_mult=1), 64, 1024),
+        ("e_b", dict(channel_mult=(1, 1, 2, 2, 4, 4), out_dilations=(), depth_mult=3), 96, 2048),
+    ]
+    for tag, topo, oc, T in encs:
+        m = UNetEncoder(32, out_channels=oc, **topo)
+        det_init_(("encoder." + tag + "." + k, v) for k, v in m.state_dict().items())
+        m.eval()
+        sd = {"encoder." + k: v.detach().clone() for k, v in m.state_dict().items()}
+        x = seeded((2, 1, T), 800 + len(out), 0.3)
+        with torch.no_grad():
+            z = m(x)
+        check("custom encoder " + tag, z, ref_cpu.unet_encoder(sd, 32, x, topology=topo))
+        assert z.shape == (2, oc, T // m.downsample_rate)
+        out[tag + ".x"], out[tag + ".z"] = x, z
+        print(f"  {tag}: {topo} z {tuple(z.shape)} rms={z.pow(2).mean().sqrt().item():.4f}")
+    save("f14_custom_topologies", **out)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     if not only or "resblocks" in only:
@@ -599,6 +648,8 @@ if __name__ == "__main__":
         gen_uncond_guidance_50()
     if not only or "mfccstack" in only:
         gen_conv_mfcc_stack()
+    if not only or "topology" in only:
+        gen_custom_topologies()
     if "unet64" in only:  # (minutes of CPU time: only on request; the committed fixture is re-verifiable with this argument)
         gen_sampler_unet64()
     if "guided64" in only:  # (BASELINE config 5 at 100 steps: about a minute of CPU time, on request)

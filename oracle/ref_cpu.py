@@ -38,8 +38,9 @@ DEPTH_MULT = 2  # unet.py:22
 # --------------------------------------------------------------------------
 
 
-def predictor_block_specs(base: int) -> Dict[str, List[dict]]:
-    """Per-ResBlock (cin, cout, scale, dilation) for down / middle / up lists."""
+def predictor_block_specs(base: int, channel_mult=CHANNEL_MULT, middle_dilations=MIDDLE_DILATIONS, depth_mult: int = DEPTH_MULT) -> Dict[str, List[dict]]:
+    """Per-ResBlock (cin, cout, scale, dilation) for down / middle / up lists (any topology UNetPredictor.__init__ takes, unet.py:17-30)."""
+    CHANNEL_MULT, MIDDLE_DILATIONS, DEPTH_MULT = tuple(channel_mult), tuple(middle_dilations), depth_mult  # noqa: N806 (shadow the defaults)
     down, middle, up = [], [], []
     stack = [base]
     cur = base
@@ -65,16 +66,19 @@ def predictor_block_specs(base: int) -> Dict[str, List[dict]]:
     return dict(down=down, middle=middle, up=up)
 
 
-def encoder_block_specs(base: int) -> List[dict]:
+def encoder_block_specs(base: int, channel_mult=CHANNEL_MULT, out_dilations=(), depth_mult: int = DEPTH_MULT) -> List[dict]:
+    """unet.py:206-220 (any topology UNetEncoder.__init__ takes, unet.py:188-196)."""
     blocks = []
     cur = base
-    last = len(CHANNEL_MULT) - 1
-    for depth, mult in enumerate(CHANNEL_MULT):
-        for _ in range(DEPTH_MULT):
+    last = len(channel_mult) - 1
+    for depth, mult in enumerate(channel_mult):
+        for _ in range(depth_mult):
             blocks.append(dict(cin=cur, cout=mult * base, scale=1.0, dil=2))
             cur = mult * base
         if depth != last:
             blocks.append(dict(cin=cur, cout=cur, scale=0.5, dil=2))
+    for d in out_dilations:
+        blocks.append(dict(cin=cur, cout=cur, scale=1.0, dil=d))
     return blocks
 
 
@@ -156,14 +160,16 @@ def unet_predictor(
     labels: Optional[Tensor] = None,
     prefix: str = "predictor",
     probe: Optional[Callable[[str, Tensor], None]] = None,
+    topology: Optional[dict] = None,
 ) -> Tensor:
-    """unet.py:118-163.  `probe(name, tensor)` sees every block output (for bisecting)."""
+    """unet.py:118-163.  `probe(name, tensor)` sees every block output (for bisecting); `topology` = dict(channel_mult=,
+    middle_dilations=, depth_mult=) for a network other than the default one."""
     p = prefix
     has_labels = (p + ".class_embed.weight") in sd
     has_cond = (p + ".cond_proj.weight") in sd
     assert (labels is None) == (not has_labels), "must provide labels iff class conditional"
     assert (cond is None) == (not has_cond), "must provide cond iff conditional"
-    specs = predictor_block_specs(base)
+    specs = predictor_block_specs(base, **(topology or {}))
 
     emb = unet_embedding(sd, ts, labels, p)
 
@@ -193,11 +199,11 @@ def unet_predictor(
     return F.conv1d(h, sd[p + ".out.1.weight"], sd[p + ".out.1.bias"], padding=1)
 
 
-def unet_encoder(sd: State, base: int, x: Tensor, prefix: str = "encoder") -> Tensor:
-    """unet.py:229-241."""
+def unet_encoder(sd: State, base: int, x: Tensor, prefix: str = "encoder", topology: Optional[dict] = None) -> Tensor:
+    """unet.py:229-241; `topology` = dict(channel_mult=, out_dilations=, depth_mult=) for a network other than the default one."""
     p = prefix
     h = F.conv1d(x, sd[p + ".in_conv.weight"], sd[p + ".in_conv.bias"], padding=1)
-    for i, spec in enumerate(encoder_block_specs(base)):
+    for i, spec in enumerate(encoder_block_specs(base, **(topology or {}))):
         h = res_block(h, sd, f"{p}.blocks.{i}", spec, None)
     h = F.gelu(group_norm(h, sd, p + ".out.0.0"))
     return F.conv1d(h, sd[p + ".out.1.weight"], sd[p + ".out.1.bias"], padding=1)

@@ -39,6 +39,39 @@ def test_param_table_is_the_reference_state_dict(lib_built):
     assert v.cond_channels == 512 and v.save_kwargs()["enc_name"] == "unet"
 
 
+def test_open_topology_param_tables(lib_built):
+    """channel_mult / depth_mult / middle_dilations / out_dilations other than the defaults (reference unet.py:17-30, 188-196): the
+    library's parameter table is the module's state dict (whose keys and shapes are the reference's, fixture F14 is made with
+    them), the downsample rate follows the level count, and what cannot be built is refused with the reason."""
+    from vq_voice_swap_amd import UNetEncoder, UNetPredictor
+
+    for kw in (dict(channel_mult=(1, 2, 2, 4), middle_dilations=(1, 6), depth_mult=1, num_labels=3),
+               dict(channel_mult=(1, 1, 2), middle_dilations=(), depth_mult=3),
+               dict(channel_mult=(1, 4, 8, 8, 16), middle_dilations=(2, 32, 5), depth_mult=2, cond_channels=64)):
+        m = UNetPredictor(32, **kw)
+        sd = m.state_dict()
+        table = _native.param_table(m._cfg())
+        assert len(table) == len(sd) and set(n for n, _ in table) == set(sd.keys()), kw
+        assert all(tuple(sd[n].shape) == s for n, s in table)
+        assert m.downsample_rate == 2 ** (len(kw["channel_mult"]) - 1)
+    for kw in (dict(channel_mult=(1, 2, 4), out_dilations=(2, 8), depth_mult=1, out_channels=64),
+               dict(channel_mult=(1, 1, 2, 2, 4, 4), out_dilations=(), depth_mult=3, out_channels=96)):
+        m = UNetEncoder(32, **kw)
+        sd = m.state_dict()
+        table = _native.param_table(m._cfg())
+        assert len(table) == len(sd) and set(n for n, _ in table) == set(sd.keys()), kw
+        assert all(tuple(sd[n].shape) == s for n, s in table)
+    # the default topology does not set the fields at all (old cfg structs keep working)
+    assert UNetPredictor(32)._cfg().topology_set == 0 and UNetEncoder(32)._cfg().topology_set == 0
+    for bad in (dict(channel_mult=(1, 1.5)), dict(channel_mult=(1, 64)), dict(depth_mult=0), dict(middle_dilations=(64,)), dict(channel_mult=(2, 2)),
+                dict(channel_mult=tuple([1] * 13))):
+        with pytest.raises(ValueError):
+            UNetPredictor(32, **bad)  # widths not multiples of 32 / beyond 1024 / depth / dilation range / head width / level count
+    cfg = UNetPredictor(32)._cfg()
+    cfg.topology_set, cfg.n_levels = 1, 0
+    assert lib_built.vqvs_param_count(cfg) < 0 and b"n_levels" in lib_built.vqvs_last_error()
+
+
 def test_checkpoint_roundtrip(tmp_path):
     m = DiffusionModel("unet", 32, num_labels=4)
     p = str(tmp_path / "m.pt")

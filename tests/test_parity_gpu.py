@@ -114,6 +114,37 @@ def test_conditioning_of_any_length_vs_oracle(dev):
         model.predictor(torch.zeros(2, 1, 4096, device=dev), torch.zeros(2, device=dev), cond=torch.zeros(2, 256, 16, device=dev), labels=labels.to(dev))
 
 
+def test_open_topology_vs_reference_fixture(golden, dev):
+    """F14: UNetPredictor / UNetEncoder with channel_mult / depth_mult / middle_dilations / out_dilations other than the defaults
+    (reference unet.py:17-30, 188-196), built by the reference's own constructors: forward outputs in every mode."""
+    from vq_voice_swap_amd import UNetEncoder, UNetPredictor
+
+    z = golden("f14_custom_topologies")
+    preds = [("p_a", dict(channel_mult=(1, 2, 2, 4), middle_dilations=(1, 6), depth_mult=1), dict(num_labels=3)),
+             ("p_b", dict(channel_mult=(1, 1, 2), middle_dilations=(), depth_mult=3), {}),
+             ("p_c", dict(channel_mult=(1, 4, 8, 8, 16), middle_dilations=(2, 32, 5), depth_mult=2), dict(cond_channels=64))]
+    for tag, topo, extra in preds:
+        m = UNetPredictor(32, **topo, **extra)
+        det_init_(("predictor." + tag + "." + k, v) for k, v in m.state_dict().items())
+        m.eval()
+        kw = {k: torch.from_numpy(z[f"{tag}.{k}"]).to(dev) for k in ("labels", "cond") if f"{tag}.{k}" in z.files}
+        want = torch.from_numpy(z[tag + ".eps"])
+        for prec, tol in MODES:
+            m.set_precision(prec)
+            got = m(torch.from_numpy(z[tag + ".x"]).to(dev), torch.from_numpy(z[tag + ".ts"]).to(dev), **kw).cpu()
+            assert rel_rms(got, want) < tol, (tag, prec, rel_rms(got, want))
+        with pytest.raises(ValueError, match="downsample rate"):
+            m(torch.zeros(1, 1, m.downsample_rate * 3 + 1, device=dev), torch.zeros(1, device=dev), **{k: v[:1] for k, v in kw.items()})
+    for tag, topo, oc in (("e_a", dict(channel_mult=(1, 2, 4), out_dilations=(2, 8), depth_mult=1), 64),
+                          ("e_b", dict(channel_mult=(1, 1, 2, 2, 4, 4), out_dilations=(), depth_mult=3), 96)):
+        m = UNetEncoder(32, out_channels=oc, **topo)
+        det_init_(("encoder." + tag + "." + k, v) for k, v in m.state_dict().items())
+        m.eval()
+        want = torch.from_numpy(z[tag + ".z"])
+        got = m(torch.from_numpy(z[tag + ".x"]).to(dev)).cpu()
+        assert got.shape == want.shape and rel_rms(got, want) < FP32_REL, (tag, rel_rms(got, want))
+
+
 def test_whole_clip_tiles_for_wide_dilations_vs_oracle(dev):
     """The middle blocks' shapes (unet.py:21, 78-88: dilation 4 .. 32 at 250 rows, 256 / 512 channels): a clip of at most 255 rows is
     one zero-padded tile of conv_ws_kernel whatever the dilation (template flag ZP) -- every dilation, clip lengths around the limits

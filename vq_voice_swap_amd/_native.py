@@ -42,7 +42,27 @@ class Cfg(C.Structure):
         ("rb_dilation", C.c_int32),
         ("rb_emb_channels", C.c_int32),
         ("reserved", C.c_int32 * 5),  # reserved[0] = 1: checkpoints trained with dropout (conv is post_cond.2)
+        # topology of predictor / encoder handles (include/vqvs.h); topology_set = 0: the reference's defaults
+        ("topology_set", C.c_int32),
+        ("n_levels", C.c_int32),
+        ("channel_mult", C.c_int32 * 12),
+        ("depth_mult", C.c_int32),
+        ("n_dilations", C.c_int32),
+        ("dilations", C.c_int32 * 12),
     ]
+
+    def set_topology(self, channel_mult, depth_mult, dilations):
+        """Describe a UNet other than the reference's default one (unet.py:17-30, 188-196)."""
+        if len(channel_mult) > 12 or len(dilations) > 12:
+            raise ValueError("the gfx950 library builds at most 12 levels and 12 middle / output dilations")
+        self.topology_set = 1
+        self.n_levels = len(channel_mult)
+        for i, m in enumerate(channel_mult):
+            self.channel_mult[i] = int(m)
+        self.depth_mult = int(depth_mult)
+        self.n_dilations = len(dilations)
+        for i, d in enumerate(dilations):
+            self.dilations[i] = int(d)
 
 
 EXPORTS = [

@@ -19,10 +19,28 @@ namespace vqvs {
 
 namespace {
 
-const int CH_MULT[9] = {1, 1, 2, 2, 2, 4, 4, 8, 8};  // unet.py:20
-const int MID_DIL[4] = {4, 8, 16, 32};               // unet.py:21
-constexpr int DEPTH_MULT = 2;                        // unet.py:22
-constexpr int NLEVEL = 9;
+// The UNets' topology (unet.py:17-30, 188-196): the reference's defaults unless the configuration carries its own
+// (vqvs_cfg.topology_set; predictor and encoder handles -- the classifier stem and the encoder predictor are built with the defaults).
+struct Topo {
+  std::vector<int> mult;  // channel_mult
+  int depth = 2;          // depth_mult
+  std::vector<int> dil;   // middle_dilations (predictor) / out_dilations (encoder)
+  int levels() const { return (int)mult.size(); }
+};
+Topo topo_of(const vqvs_cfg& c) {
+  Topo t;
+  const bool custom = c.topology_set != 0 && (c.kind == VQVS_KIND_PREDICTOR || c.kind == VQVS_KIND_ENCODER);
+  if (custom) {
+    t.mult.assign(c.channel_mult, c.channel_mult + std::max(0, std::min(c.n_levels, (int)VQVS_MAX_LEVELS)));
+    t.depth = c.depth_mult;
+    t.dil.assign(c.dilations, c.dilations + std::max(0, std::min(c.n_dilations, 12)));
+  } else {
+    t.mult = {1, 1, 2, 2, 2, 4, 4, 8, 8};  // unet.py:20
+    t.depth = 2;                            // unet.py:22
+    if (c.kind != VQVS_KIND_ENCODER) t.dil = {4, 8, 16, 32};  // unet.py:21 (UNetEncoder: out_dilations = (), unet.py:192)
+  }
+  return t;
+}
 
 struct BlockSpec {
   std::string prefix;
@@ -30,11 +48,12 @@ struct BlockSpec {
   bool cat;
 };
 
-void predictor_blocks(int base, std::vector<BlockSpec>& down, std::vector<BlockSpec>& mid, std::vector<BlockSpec>& up) {
+void predictor_blocks(int base, const Topo& tp, std::vector<BlockSpec>& down, std::vector<BlockSpec>& mid, std::vector<BlockSpec>& up) {
+  const int NLEVEL = tp.levels(), DEPTH_MULT = tp.depth;
   std::vector<int> stack{base};
   int cur = base;
   for (int depth = 0; depth < NLEVEL; ++depth) {
-    const int mult = CH_MULT[depth];
+    const int mult = tp.mult[depth];
     for (int i = 0; i < DEPTH_MULT; ++i) {
       down.push_back({"down_blocks." + std::to_string(down.size()), cur, mult * base, RESIZE_NONE, 2, false});
       cur = mult * base;
@@ -45,9 +64,9 @@ void predictor_blocks(int base, std::vector<BlockSpec>& down, std::vector<BlockS
       stack.push_back(cur);
     }
   }
-  for (int i = 0; i < 4; ++i) mid.push_back({"middle_blocks." + std::to_string(i), cur, cur, RESIZE_NONE, MID_DIL[i], false});
+  for (size_t i = 0; i < tp.dil.size(); ++i) mid.push_back({"middle_blocks." + std::to_string(i), cur, cur, RESIZE_NONE, tp.dil[i], false});
   for (int depth = NLEVEL - 1; depth >= 0; --depth) {
-    const int mult = CH_MULT[depth];
+    const int mult = tp.mult[depth];
     for (int i = 0; i < DEPTH_MULT + 1; ++i) {
       const int sk = stack.back();
       stack.pop_back();
@@ -58,23 +77,28 @@ void predictor_blocks(int base, std::vector<BlockSpec>& down, std::vector<BlockS
   }
 }
 
-void encoder_blocks(int base, std::vector<BlockSpec>& blocks) {
+int encoder_blocks(int base, const Topo& tp, std::vector<BlockSpec>& blocks) {  // returns the width of the last block
+  const int NLEVEL = tp.levels(), DEPTH_MULT = tp.depth;
   int cur = base;
   for (int depth = 0; depth < NLEVEL; ++depth) {
-    const int mult = CH_MULT[depth];
+    const int mult = tp.mult[depth];
     for (int i = 0; i < DEPTH_MULT; ++i) {
       blocks.push_back({"blocks." + std::to_string(blocks.size()), cur, mult * base, RESIZE_NONE, 2, false});
       cur = mult * base;
     }
     if (depth != NLEVEL - 1) blocks.push_back({"blocks." + std::to_string(blocks.size()), cur, cur, RESIZE_AVG2, 2, false});
   }
+  for (int d : tp.dil) blocks.push_back({"blocks." + std::to_string(blocks.size()), cur, cur, RESIZE_NONE, d, false});  // out_dilations, unet.py:219-220
+  return cur;
 }
 
 // ClassifierStem (classifier.py:79-96): like the encoder, but FiLM-conditioned and with a x0.5 block after EVERY level
 void classifier_blocks(int base, std::vector<BlockSpec>& blocks) {
+  const Topo tp = topo_of(vqvs_cfg{});  // (classifier.py:52-58: the same defaults)
+  const int NLEVEL = tp.levels(), DEPTH_MULT = tp.depth;
   int cur = base;
   for (int depth = 0; depth < NLEVEL; ++depth) {
-    const int mult = CH_MULT[depth];
+    const int mult = tp.mult[depth];
     for (int i = 0; i < DEPTH_MULT; ++i) {
       blocks.push_back({"stem.blocks." + std::to_string(blocks.size()), cur, mult * base, RESIZE_NONE, 2, false});
       cur = mult * base;
@@ -856,14 +880,35 @@ int tensor_rows(int Lbase, int lshift) { return shiftL(Lbase, lshift); }
 // so neither a very large --classifier-scale can overflow fp16 nor a very small one push the gradients into its subnormals.
 float grad_scale(int precision) { return precision == VQVS_PREC_F16 ? 1024.0f : 1.0f; }
 
+int unet_rate(const vqvs_cfg& c) {  // UNetPredictor / UNetEncoder.downsample_rate (unet.py:182-184, 243-245): 2^(len(channel_mult) - 1)
+  return 1 << (topo_of(c).levels() - 1);
+}
+
 int gn_groups(int ch) {  // unet.py:345-349
   int g = 32;
   while (ch % g) g /= 2;
   return g;
 }
 
+static int check_topology(const vqvs_cfg& c) {
+  if (c.topology_set && c.kind != VQVS_KIND_PREDICTOR && c.kind != VQVS_KIND_ENCODER)
+    VQVS_FAIL(VQVS_ERR_ARG, "a custom topology is built for predictor and encoder handles only (kind %d)", c.kind);
+  if (c.topology_set) {
+    if (c.n_levels < 1 || c.n_levels > VQVS_MAX_LEVELS) VQVS_FAIL(VQVS_ERR_ARG, "n_levels must be in 1..%d (got %d)", VQVS_MAX_LEVELS, c.n_levels);
+    for (int i = 0; i < c.n_levels; ++i)
+      if (c.channel_mult[i] < 1 || c.channel_mult[i] * c.base_channels > 1024)
+        VQVS_FAIL(VQVS_ERR_ARG, "channel_mult[%d] = %d: widths must be in base_channels..1024", i, c.channel_mult[i]);
+    if (c.depth_mult < 1 || c.depth_mult > 8) VQVS_FAIL(VQVS_ERR_ARG, "depth_mult must be in 1..8 (got %d)", c.depth_mult);
+    if (c.n_dilations < 0 || c.n_dilations > 12) VQVS_FAIL(VQVS_ERR_ARG, "at most 12 middle / output dilations (got %d)", c.n_dilations);
+    for (int i = 0; i < c.n_dilations; ++i)
+      if (c.dilations[i] < 1 || c.dilations[i] > 32) VQVS_FAIL(VQVS_ERR_ARG, "dilation %d is outside 1..32", c.dilations[i]);
+  }
+  return 0;
+}
+
 int enumerate_params(const vqvs_cfg& c, std::vector<ParamDef>& out) {
   out.clear();
+  if (int e = check_topology(c)) return e;
   const int base = c.base_channels;
   const bool drop = cfg_dropout(c);
   if (c.kind == VQVS_KIND_PREDICTOR || c.kind == VQVS_KIND_ENCPRED) {
@@ -880,7 +925,7 @@ int enumerate_params(const vqvs_cfg& c, std::vector<ParamDef>& out) {
     out.push_back({"in_conv.weight", {base, c.in_channels, 3}});
     out.push_back({"in_conv.bias", {base}});
     std::vector<BlockSpec> d, mdl, u;
-    predictor_blocks(base, d, mdl, u);
+    predictor_blocks(base, topo_of(c), d, mdl, u);
     for (auto& s : d) block_params(out, s.prefix, s, E, drop);
     for (auto& s : mdl) block_params(out, s.prefix, s, E, drop);
     for (auto& s : u) block_params(out, s.prefix, s, E, drop);
@@ -897,9 +942,8 @@ int enumerate_params(const vqvs_cfg& c, std::vector<ParamDef>& out) {
     out.push_back({"in_conv.weight", {base, c.in_channels, 3}});
     out.push_back({"in_conv.bias", {base}});
     std::vector<BlockSpec> blocks;
-    encoder_blocks(base, blocks);
+    const int cur = encoder_blocks(base, topo_of(c), blocks);
     for (auto& s : blocks) block_params(out, s.prefix, s, 0, false);
-    const int cur = 8 * base;
     out.push_back({"out.0.0.weight", {cur}});
     out.push_back({"out.0.0.bias", {cur}});
     out.push_back({"out.1.weight", {c.out_channels, cur, 3}});
@@ -972,7 +1016,11 @@ static int check_cfg(const vqvs_cfg& c) {
     if (c.max_T < 2 * 400) VQVS_FAIL(VQVS_ERR_ARG, "max_T must be at least 800 samples");
     return 0;
   }
-  if (c.max_T % 256) VQVS_FAIL(VQVS_ERR_ARG, "max_T must be a multiple of 256 (got %d)", c.max_T);
+  if (int e = check_topology(c)) return e;
+  {
+    const int rate = unet_rate(c);
+    if (c.max_T % rate) VQVS_FAIL(VQVS_ERR_ARG, "max_T must be a multiple of the downsample rate %d (got %d)", rate, c.max_T);
+  }
   // the kernels address rows of one clip with 32-bit byte offsets (buffer loads): the widest per-clip tensor must stay below 2 GiB
   if ((long long)c.max_T * c.base_channels * 8 > 0x7fffffffLL)
     VQVS_FAIL(VQVS_ERR_ARG, "max_T=%d is too long for base_channels=%d (a clip's top-level tensor would exceed 2 GiB)", c.max_T, c.base_channels);
@@ -1048,7 +1096,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
     b.persist = encpred;
     const int E = 4 * base;
     std::vector<BlockSpec> d, mdl, u;
-    predictor_blocks(base, d, mdl, u);
+    predictor_blocks(base, topo_of(c), d, mdl, u);
     for (auto* v : {&d, &mdl, &u})
       for (auto& sp : *v) sp.prefix = px + sp.prefix;
     // ---- embedding + all blocks' FiLM rows
@@ -1583,7 +1631,8 @@ int build_model(vqvs_model* m, const float* const* hp) {
     m->add_op([=](const RunCtx& r) -> int { return launch_ntc_to_nct(bp->act(o.off), r.out, r.B, OC, shiftL(r.Lbase, LEN_HALF), 0, r.st); });
   } else {  // encoder (unet.py:229-241)
     std::vector<BlockSpec> blocks;
-    encoder_blocks(base, blocks);
+    const int cur = encoder_blocks(base, topo_of(c), blocks);
+    const int out_ls = topo_of(c).levels() - 1;  // the output has T / downsample_rate rows
     TensorH h = b.new_tensor(base, 0, false, true);
     {
       const size_t w = b.blob_f32("in_conv.weight"), bi = b.blob_f32("in_conv.bias");
@@ -1610,10 +1659,9 @@ int build_model(vqvs_model* m, const float* const* hp) {
       h = o;
       b.tap(s.prefix, h);
     }
-    const int cur = 8 * base;
     const size_t ss = b.alloc_ss(cur);
     b.add_gn({h}, "out.0.0", false, 0, 0, 0, ss);
-    TensorH o = b.new_tensor(c.out_channels, 8, true, false);
+    TensorH o = b.new_tensor(c.out_channels, out_ls, true, false);
     PackedConv pk(prec);
     Builder::SegSpec g{h, 0, cur, 3, 1, RESIZE_NONE, true, ss, cur, 0, 0};
     g.w_off = pk.append(b.P("out.1.weight"), c.out_channels, cur, 3, 0, cur);
@@ -1621,7 +1669,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
     b.add_conv({g}, pk, std::vector<float>(bb, bb + c.out_channels), c.out_channels, o, nullptr, 0);
     const int OC = c.out_channels;
     m->meta.push_back({"ntc_to_nct", "", 0, 0, 0});
-    m->add_op([=](const RunCtx& r) -> int { return launch_ntc_to_nct(bp->act(o.off), r.out, r.B, OC, r.Lbase >> 8, 0, r.st); });
+    m->add_op([=](const RunCtx& r) -> int { return launch_ntc_to_nct(bp->act(o.off), r.out, r.B, OC, r.Lbase >> out_ls, 0, r.st); });
   }
 
   for (auto& mt : m->meta) {

@@ -28,6 +28,21 @@ MIDDLE_DILATIONS = (4, 8, 16, 32)
 SUPPORTED_BASE_CHANNELS = (32, 64, 128)
 
 
+def check_topology(base_channels: int, channel_mult, depth_mult: int, dilations) -> None:
+    """What the native schedule builds of the reference's open topology (models/unet.py:17-30, 188-196): any channel_mult /
+    depth_mult / middle_dilations / out_dilations whose widths are multiples of 32 up to 1024, at most 12 levels, depth_mult 1..8,
+    dilations 1..32.  Fail here, with the reason, rather than at handle creation."""
+    if not 1 <= len(channel_mult) <= 12:
+        raise ValueError(f"channel_mult must have 1..12 entries (got {len(channel_mult)})")
+    for m in channel_mult:
+        if int(m) != m or m < 1 or (m * base_channels) % 32 or m * base_channels > 1024:
+            raise ValueError(f"channel_mult entry {m}: widths must be multiples of 32 in base_channels..1024")
+    if int(depth_mult) != depth_mult or not 1 <= depth_mult <= 8:
+        raise ValueError(f"depth_mult must be an integer in 1..8 (got {depth_mult})")
+    if len(dilations) > 12 or any(int(d) != d or not 1 <= d <= 32 for d in dilations):
+        raise ValueError(f"dilations must be at most 12 integers in 1..32 (got {tuple(dilations)})")
+
+
 def check_base_channels(base_channels: int) -> None:
     """The native schedule covers the reference's two published widths and 128; the reference itself accepts any
     `base_channels` (models/unet.py:17-30).  Fail here, with the reason, rather than at handle creation."""
@@ -264,9 +279,10 @@ class UNetPredictor(_NativeModule):
                  cond_channels: Optional[int] = None, num_labels: Optional[int] = None,
                  in_channels: int = 1, out_channels: int = 1, dropout: float = 0.0):
         super().__init__()
-        if tuple(channel_mult) != CHANNEL_MULT or tuple(middle_dilations) != MIDDLE_DILATIONS or depth_mult != 2:
-            raise ValueError("the gfx950 library implements the reference's default UNet topology only")
         check_base_channels(base_channels)
+        check_topology(base_channels, tuple(channel_mult), depth_mult, tuple(middle_dilations))
+        if channel_mult[0] != 1:  # (the reference constructs such a model and fails in forward: its output head normalises base_channels, unet.py:113)
+            raise ValueError("channel_mult[0] must be 1: the output head (GroupNorm + conv) is built for base_channels")
         self.base_channels = base_channels
         self.channel_mult = tuple(channel_mult)
         self.middle_dilations = tuple(middle_dilations)
@@ -323,6 +339,8 @@ class UNetPredictor(_NativeModule):
         cfg.num_labels = self.num_labels or 0
         cfg.reserved[0] = 1 if self.dropout else 0
         cfg.reserved[3] = self._cond_code
+        if (self.channel_mult, self.middle_dilations, self.depth_mult) != (CHANNEL_MULT, MIDDLE_DILATIONS, 2):
+            cfg.set_topology(self.channel_mult, self.depth_mult, self.middle_dilations)
         return cfg
 
     def forward(self, x: torch.Tensor, ts: torch.Tensor, cond: Optional[torch.Tensor] = None,
@@ -394,11 +412,11 @@ class UNetEncoder(_NativeModule):
     def __init__(self, base_channels: int, channel_mult: Tuple[int, ...] = CHANNEL_MULT, out_dilations: Tuple[int, ...] = (),
                  depth_mult: int = 2, in_channels: int = 1, out_channels: int = 512):
         super().__init__()
-        if tuple(channel_mult) != CHANNEL_MULT or tuple(out_dilations) or depth_mult != 2:
-            raise ValueError("the gfx950 library implements the reference's default UNetEncoder topology only")
         check_base_channels(base_channels)
+        check_topology(base_channels, tuple(channel_mult), depth_mult, tuple(out_dilations))
         self.base_channels = base_channels
         self.channel_mult = tuple(channel_mult)
+        self.out_dilations = tuple(out_dilations)
         self.depth_mult = depth_mult
         self.in_channels = in_channels
         self.out_channels = out_channels
@@ -412,6 +430,8 @@ class UNetEncoder(_NativeModule):
                 cur = mult * C
             if depth != last:
                 blocks.append(ResBlock(cur, None, scale_factor=0.5))
+        for d in self.out_dilations:  # unet.py:219-220
+            blocks.append(ResBlock(cur, None, dilation=d))
         self.blocks = nn.ModuleList(blocks)
         self.out = _seq(_seq(nn.GroupNorm(_groups(cur), cur), None), nn.Conv1d(cur, out_channels, 3, padding=1))
 
@@ -421,6 +441,8 @@ class UNetEncoder(_NativeModule):
         cfg.base_channels = self.base_channels
         cfg.in_channels = self.in_channels
         cfg.out_channels = self.out_channels
+        if (self.channel_mult, self.out_dilations, self.depth_mult) != (CHANNEL_MULT, (), 2):
+            cfg.set_topology(self.channel_mult, self.depth_mult, self.out_dilations)
         return cfg
 
     def forward(self, x: torch.Tensor, use_checkpoint: bool = False) -> torch.Tensor:
@@ -432,7 +454,7 @@ class UNetEncoder(_NativeModule):
             raise ValueError(f"T={T} is not a multiple of the UNet downsample rate {self.downsample_rate}")
         x = x.detach().to(torch.float32).contiguous()
         h = self.handle(x.device, B, T)
-        z = torch.empty(B, self.out_channels, T // 256, device=x.device, dtype=torch.float32)
+        z = torch.empty(B, self.out_channels, T // self.downsample_rate, device=x.device, dtype=torch.float32)
         with torch.cuda.device(x.device):
             _native.check(_native.lib().vqvs_encoder_forward(h.ptr, x.data_ptr(), z.data_ptr(), B, T, _native._stream_ptr()))
         return z
