@@ -75,7 +75,7 @@ def cpu_baseline(base: int, T: int, sample_steps: int):
     cfg = _native.Cfg()
     cfg.kind, cfg.base_channels, cfg.in_channels, cfg.out_channels = 0, base, 1, 1
     sd = {"predictor." + n: det_tensor("predictor." + n, s) for n, s in _native.param_table(cfg)}
-    nb, ns = (4, 6) if base == 64 else (4, 12)  # ~10-20 s of CPU work on 32 threads
+    nb, ns = (8, 5) if base == 64 else (8, 10)  # unet64, 8 clips x 5 steps, extrapolated linearly (~25 s of CPU work on 32 threads)
     g = torch.Generator().manual_seed(0)
     x = torch.randn(nb, 1, T, generator=g)
     noises = [torch.randn(nb, 1, T, generator=g) for _ in range(ns)]

@@ -27,8 +27,58 @@ def test_wav_roundtrip_matches_reference_quantisation(tmp_path):
     got = np.concatenate([a, b])
     want = (np.clip(x, -1, 1) * (2 ** 15 - 1)).astype("int16").astype("float32") / 2 ** 15  # dataset.py:296-298, 222-223
     assert np.array_equal(got, want)
-    with pytest.raises(ValueError, match="sample rate"):
-        ChunkReader(p, 8000)
+
+
+def _write_wav(path, x, rate, bits, channels=1, float_fmt=False):
+    import struct
+
+    x = np.asarray(x, dtype=np.float64)
+    frames = np.stack([x * (1.0 if c == 0 else 0.5) for c in range(channels)], axis=1)  # (other channels: the same tone at half level)
+    if float_fmt:
+        body, tag = frames.astype("<f4").tobytes(), 3
+    elif bits == 8:
+        body, tag = (np.clip(np.rint(frames * 128) + 128, 0, 255)).astype(np.uint8).tobytes(), 1
+    elif bits == 16:
+        body, tag = np.clip(np.rint(frames * 2 ** 15), -2 ** 15, 2 ** 15 - 1).astype("<i2").tobytes(), 1
+    elif bits == 24:
+        v = np.clip(np.rint(frames * 2 ** 23), -2 ** 23, 2 ** 23 - 1).astype(np.int64).reshape(-1) & 0xFFFFFF
+        body, tag = np.stack([v & 0xFF, (v >> 8) & 0xFF, (v >> 16) & 0xFF], axis=1).astype(np.uint8).tobytes(), 1
+    else:
+        body, tag = np.clip(np.rint(frames * 2 ** 31), -2 ** 31, 2 ** 31 - 1).astype("<i4").tobytes(), 1
+    bps = 4 if float_fmt else bits // 8
+    fmt = struct.pack("<HHIIHH", tag, channels, rate, rate * channels * bps, channels * bps, bps * 8)
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 4 + 8 + len(fmt) + 8 + len(body)) + b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt
+                + b"data" + struct.pack("<I", len(body)) + body)
+
+
+def test_reader_decodes_downmixes_and_resamples(tmp_path):
+    """What the reference's `ffmpeg -ar <rate> -ac 1` pipe does for every input (dataset.py:177-203): other sample rates, channel
+    counts and sample encodings come back as mono samples at the requested rate on the s16 grid."""
+    dur, f0 = 0.5, 440.0
+    for i, (rate, bits, ch, flt) in enumerate([(44100, 16, 2, False), (48000, 24, 1, False), (8000, 8, 1, False), (22050, 32, 2, False),
+                                               (32000, 32, 1, True), (16000, 24, 3, False)]):
+        t = np.arange(int(rate * dur)) / rate
+        p = str(tmp_path / f"in{i}.wav")
+        _write_wav(p, 0.6 * np.sin(2 * np.pi * f0 * t), rate, bits, ch, flt)
+        r = ChunkReader(p, 16000)
+        x = r.read(10 ** 6)
+        assert r.read(1) is None
+        r.close()
+        n = int(16000 * dur)
+        assert abs(len(x) - n) <= 1, (rate, len(x))
+        gain = np.mean([1.0] + [0.5] * (ch - 1))  # the mean of the channels
+        want = gain * 0.6 * np.sin(2 * np.pi * f0 * np.arange(len(x)) / 16000)
+        tol = 2e-2 if bits == 8 else 2e-3
+        assert np.abs(x - want)[200:-200].max() < tol, (rate, bits, ch, np.abs(x - want)[200:-200].max())
+        assert np.array_equal(x * 2 ** 15, np.rint(x * 2 ** 15))  # on the s16 grid, as the reference's pipe output
+    bad = tmp_path / "clip.mp3"
+    bad.write_bytes(b"ID3" + bytes(64))
+    import shutil
+
+    if shutil.which("ffmpeg") is None:
+        with pytest.raises(ValueError, match="ffmpeg"):
+            ChunkReader(str(bad), 16000)
 
 
 def test_ulaw_codec():
