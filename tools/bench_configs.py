@@ -3,6 +3,8 @@ cfg 2 unet32 B=64; cfg 3 unet64 B=64 (the bench.py workload, for reference); cfg
 VQ + conditional unet64 decoder) B=32; cfg 5 unet64 + classifier32 guidance, 100 steps, B=32.  One JSON object on stdout;
 every entry carries the end-to-end HBM fraction = algorithmic (Model A) bytes of all forward / backward passes of the run /
 wall time / 8 TB/s.  `--only cfg5 --precision fp16 --reps 1` is what tools/measure.sh profiles under rocprofv3."""
+import os
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # kernel arguments in device memory: a process-level HIP switch, before the runtime starts (INTEGRATION.md)
 import argparse
 import json
 import os

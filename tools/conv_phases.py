@@ -3,6 +3,8 @@
 
     VQVS_LIB_PATH=vq_voice_swap_amd/libvqvs_timing.so python tools/conv_phases.py
 """
+import os
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # kernel arguments in device memory: a process-level HIP switch, before the runtime starts (INTEGRATION.md)
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

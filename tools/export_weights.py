@@ -5,6 +5,8 @@
 
 Layout: magic "VQVSW1\\0\\0", int32 base_channels, int32 n_tensors, then per tensor: int32 name_len, name bytes,
 int64 numel, numel float32 values."""
+import os
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # kernel arguments in device memory: a process-level HIP switch, before the runtime starts (INTEGRATION.md)
 import os, struct, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,5 +1,7 @@
 """Waveform RMS of the VQ-VAE decode fixture F8 (5 steps, constrained, 2 x 4096) per precision mode -- the thinnest margin of the
 1e-3 gate, used to bisect numerics changes:  [VQVS_LIB_PATH=...] python tools/f8_rms.py"""
+import os
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # kernel arguments in device memory: a process-level HIP switch, before the runtime starts
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,6 +1,8 @@
 """Randomised ResBlock parity sweep (HIP vs oracle): random channel counts, lengths (incl. tile-boundary cases),
 dilations, resizes, FiLM on/off, batch sizes, all three precision modes.  Developer tool; tests/ hold the fixed cases.
     python tools/fuzz_resblock.py [seed] [cases] [big]      ("big": every fourth case is a long, many-clip launch)"""
+import os
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # kernel arguments in device memory: a process-level HIP switch, before the runtime starts
 import os, random, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

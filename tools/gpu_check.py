@@ -1,5 +1,7 @@
 """Developer diagnostic: run every golden case through the HIP path on cuda:0 and print error tables
 (keeps going on failure).  Not a test; tests/ hold the asserted versions."""
+import os
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # kernel arguments in device memory: a process-level HIP switch, before the runtime starts
 import os, sys, time, traceback
 import numpy as np
 import torch

@@ -3,6 +3,8 @@ and the CPU oracle -- the numbers DESIGN.md section 4 quotes and the tolerances 
 
     python tools/precision_check.py [--modes fp32,fp16,bf16] [--skip-unet64]
 """
+import os
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # kernel arguments in device memory: a process-level HIP switch, before the runtime starts (INTEGRATION.md)
 import argparse
 import os
 import sys

@@ -3,6 +3,8 @@
    h1  = store the block-internal tensor h1 in bf16
    res = store the residual stream (block outputs, in_conv output) in bf16
 Reports the relative error of eps (unet32, 2 x 16384 samples) against the unrounded oracle."""
+import os
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # kernel arguments in device memory: a process-level HIP switch, before the runtime starts (INTEGRATION.md)
 import os, sys, itertools
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,4 +1,6 @@
 """Per-kernel table of one UNet forward (live hipEvent timing): shape, ms, achieved GB/s and TFLOP/s."""
+import os
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # kernel arguments in device memory: a process-level HIP switch, before the runtime starts
 import argparse, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,5 +1,6 @@
 """One-rank RCCL self-check of the collectives the sampler uses (init, barrier, all_reduce MAX, all_gather)."""
 import os, torch, torch.distributed as dist
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 lr = int(os.environ.get("LOCAL_RANK", "0"))
 torch.cuda.set_device(lr)
 dist.init_process_group("nccl", device_id=torch.device("cuda", lr))

@@ -1,4 +1,6 @@
 """Run one ResBlock a few times (a target for rocprofv3 --pmc / --kernel-trace):  python tools/run_resblock.py cin cout L B [reps] [prec]"""
+import os
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # kernel arguments in device memory: a process-level HIP switch, before the runtime starts
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

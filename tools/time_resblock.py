@@ -1,5 +1,7 @@
 """Time one ResBlock (both convolutions + the small kernels around them) in isolation:  python tools/time_resblock.py cin cout L B [prec]
 Short bursts (5 forwards after a pause) and a sustained run (200 forwards) -- the difference is the clock the chip sustains."""
+import os
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # kernel arguments in device memory: a process-level HIP switch, before the runtime starts
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

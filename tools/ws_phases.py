@@ -3,6 +3,8 @@ instrumented library (`make -C vq_voice_swap_amd/csrc timing` -> libvqvs_timing.
 
     VQVS_LIB_PATH=vq_voice_swap_amd/libvqvs_timing.so python tools/ws_phases.py ["((cin, cout, L, B), ...)" [fp16|bf16|fp32]]
 """
+import os
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # kernel arguments in device memory: a process-level HIP switch, before the runtime starts (INTEGRATION.md)
 import ast, ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
