@@ -8,6 +8,7 @@
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float gelu7(float v) {
@@ -78,8 +79,37 @@ __global__ __launch_bounds__(1024) void k(float* out, int iters, float seed) {
     const int wr = wc * 64 + l31;
     for (int ks = 0; ks < 2; ++ks) boff[ks] = 16384 + wr * 64 + (((ks * 2 + hh) ^ ((wr >> 2) & 3)) << 4);
     const int d = (int)seed + 1;
+    f32x4v acc4[4][4];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int r = 0; r < 4; ++r) acc4[i][j][r] = 0.f;
+    const int l15 = lane & 15, kg = lane >> 4;
     for (int it = 0; it < iters; ++it) {
-      if (MODE & 2) {
+      if ((MODE & 2) && CM >= 5) {
+        // 16x16x32 MFMAs (4 passes each): per tap one k-step of 32 = 4 A fragments (16 rows each) + 4 B fragments (16 channels each),
+        // 16 MFMAs -- the same fragment bytes and the same FLOPs as 2 k-steps x (2 A + 2 B, 4 MFMAs of 32x32x16)
+        const char* const sb = smem + (it & 1) * 40960;
+        int row = wt * 64 + l15;
+        for (int kk = 0; kk < 3; ++kk, row += d) {
+          const char* const wk = sb + 16384 + kk * (128 * 64);
+          f16x8 xa[4], xb[4];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const int r = row + m * 16, c = wc * 64 + m * 16 + l15;
+            if (CM == 5) {
+              xa[m] = __builtin_bit_cast(f16x8, u32x4{(unsigned)r, 0x3c003c00u, 0x38003800u, 0x34003400u});
+              xb[m] = __builtin_bit_cast(f16x8, u32x4{0x3c003c00u, (unsigned)c, 0x38003800u, 0x34003400u});
+              asm volatile("" : "+v"(xa[m]), "+v"(xb[m]));
+            } else {
+              xa[m] = *reinterpret_cast<const f16x8*>(sb + r * 64 + ((kg ^ ((r >> 2) & 3)) << 4));
+              xb[m] = *reinterpret_cast<const f16x8*>(wk + c * 64 + ((kg ^ ((c >> 2) & 3)) << 4));
+            }
+          }
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc4[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[m], xb[n], acc4[m][n], 0, 0, 0);
+        }
+      }
+      if ((MODE & 2) && CM < 5) {
         const char* const sb = smem + (it & 1) * 40960;
         int row = wt * 64 + l31;
         for (int kk = 0; kk < 3; ++kk, row += d) {
@@ -124,6 +154,7 @@ __global__ __launch_bounds__(1024) void k(float* out, int iters, float seed) {
       }
     }
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) res += acc[i][j][r];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int r = 0; r < 4; ++r) res += acc4[i][j][r];
   }
   out[blockIdx.x * 1024 + tid] = res;
 }
@@ -159,5 +190,7 @@ int main() {
   printf("  MFMAs on register operands  %7.1f %7.1f\n", run<6, 2, 2>(), run<7, 2, 2>());
   printf("  fragment reads only         %7.1f %7.1f\n", run<6, 2, 3>(), run<7, 2, 3>());
   printf("  AGPRs + register operands   %7.1f %7.1f\n", run<6, 2, 4>(), run<7, 2, 4>());
+  printf("  16x16x32 MFMAs, register operands %7.1f %7.1f\n", run<6, 2, 5>(), run<7, 2, 5>());
+  printf("  16x16x32 MFMAs, fragment reads    %7.1f %7.1f\n", run<6, 2, 6>(), run<7, 2, 6>());
   return 0;
 }

@@ -15,7 +15,8 @@ from vq_voice_swap_amd.unet import ResBlockModule
 from vq_voice_swap_amd.det_init import det_init_
 
 P_PH = ["wait loads (vmcnt)", "prologue + ds_write", "load cursor (prepare)", "lgkmcnt + barrier", "issue next loads"]
-C_PH = ["tile start: store + bias", "weight DMA issue", "ds_read + MFMA", "tile end: stats/round/LDS", "vmcnt + barrier"]
+C_PH = ["tile start: store + bias", "weight DMA issue", "ds_read + MFMA", "tile end: stats/round/LDS", "vmcnt + barrier", "last tile's store (after the loop)",
+        "look-ahead GroupNorm table"]
 L = _native.lib()
 L.vqvs_debug_ws_timing.argtypes = [C.c_void_p, C.c_int]
 dev = torch.device("cuda:0")
@@ -49,7 +50,7 @@ def run(cin, cout, Lx, B, prec="fp16", dil=2, emb=256):
     if t[22]:
         print(f"   startup (ticks per sampled workgroup and launch): entry -> requests out / tables {t[22] / cw:.0f}, -> first barrier {t[23] / cw:.0f}, "
               f"-> weights landed {t[24] / cw:.0f}, -> loop starts {t[25] / cw:.0f}; whole workgroup {t[20] / cw:.0f}")
-    ptot, ctot = sum(t[0:5]), sum(t[8:13])
+    ptot, ctot = sum(t[0:5]), sum(t[8:15])
     print(f"   producers: {ptot / steps:8.0f} ticks per step")
     for name, v in zip(P_PH, t[0:5]):
         print(f"      {name:28s} {v / steps:8.0f}  {100 * v / ptot:5.1f}%")
@@ -57,7 +58,7 @@ def run(cin, cout, Lx, B, prec="fp16", dil=2, emb=256):
         return
     csteps = steps * cw / pw
     print(f"   consumers: {ctot / csteps:8.0f} ticks per step")
-    for name, v in zip(C_PH, t[8:13]):
+    for name, v in zip(C_PH, t[8:15]):
         print(f"      {name:28s} {v / csteps:8.0f}  {100 * v / ctot:5.1f}%")
 
 

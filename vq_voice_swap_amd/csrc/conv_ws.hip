@@ -363,16 +363,17 @@ __global__ __launch_bounds__((ws_threads<T, ROWS>())) void conv_ws_kernel(const 
     int cur_xf = 0, cur_avg = 0, cur_edge = 0;  // (wave-uniform parts of meta, kept scalar)
     int ss_clip = -1;  // clip whose (scale, shift) table was written last
     unsigned cur_valid = 0;
-    auto refresh_ss = [&]() {
+    bool ss_defer = true;  // start-up: the first clip's table is copied AFTER the first three chunk loads are on their way (below)
+    auto refresh_ss = [&](int clip) {
       // first chunk of a new clip: its (scale, shift) rows (every prologue segment's) go to LDS once -- the producers then read
       // them with ds_read instead of four more global loads per chunk and thread.  Slot b % ring: chunks of at most `ring`
       // clips are in flight (host: ring = 4 when a clip can take fewer than four steps).
-      char* const tab = smem + SS_OFF + (lt.b & (a.ss_ring - 1)) * a.ss_bytes;
+      char* const tab = smem + SS_OFF + (clip & (a.ss_ring - 1)) * a.ss_bytes;
       if (a.gn.nsrc > 0) return;  // (the consumers build the tables of a launch with a fused GroupNorm)
       for (int sg = 0; sg < a.nseg; ++sg) {
         const WsSeg& g = a.seg[sg];
         if (g.ss == nullptr) continue;
-        const char* const row = reinterpret_cast<const char*>(g.ss + (size_t)((unsigned)lt.b * (unsigned)g.ss_stride + (unsigned)g.ss_c0));
+        const char* const row = reinterpret_cast<const char*>(g.ss + (size_t)((unsigned)clip * (unsigned)g.ss_stride + (unsigned)g.ss_c0));
         for (int o = pt * 16; o < g.nch * 256; o += NPT * 16) *reinterpret_cast<f32x4*>(tab + g.ss_lds + o) = *reinterpret_cast<const f32x4*>(row + o);
       }
     };
@@ -394,7 +395,7 @@ __global__ __launch_bounds__((ws_threads<T, ROWS>())) void conv_ws_kernel(const 
       cur_avg = f.rsz == RESIZE_AVG2 ? 1 : 0;
       if (__builtin_expect(lseg == 0 && lt.b != ss_clip, 0)) {
         ss_clip = lt.b;
-        refresh_ss();
+        if (!ss_defer) refresh_ss(lt.b);
       }
       cur.ssaddr = SS_OFF + (lt.b & (a.ss_ring - 1)) * a.ss_bytes + f.ss_lds + oct * 64;
       cur_xf = f.ss != nullptr ? 1 : 0;
@@ -404,6 +405,7 @@ __global__ __launch_bounds__((ws_threads<T, ROWS>())) void conv_ws_kernel(const 
       nx = fetch(lseg + 1 == a.nseg ? 0 : lseg + 1);
     };
     enter();
+    ss_defer = false;
     auto prepare = [&]() -> Prep {
       Prep pr = cur;
       pr.meta = cur_valid | (unsigned)(cur_xf | (cur_avg << 4) | (cur_edge << 5));
@@ -623,6 +625,10 @@ __global__ __launch_bounds__((ws_threads<T, ROWS>())) void conv_ws_kernel(const 
       issue(R1, p1);
       const Prep p2 = prepare();
       issue(R2, p2);
+      // The first clip's (scale, shift) rows: a round trip to global memory that used to complete (load -> LDS) before the first
+      // activation load was even issued; behind the three chunk loads both latencies pass together.  (The cursor may have entered
+      // the next clip during the three prepare() calls: that table was copied there, ss_defer being off after the first enter.)
+      refresh_ss(first.b);
     }
     // The first clip's (scale, shift) table -- copied above, or built by the consumer waves (fused GroupNorm) -- is visible from
     // here; the consumers match this barrier.  The first three chunk loads are already in flight behind it.
@@ -706,6 +712,14 @@ __global__ __launch_bounds__((ws_threads<T, ROWS>())) void conv_ws_kernel(const 
         const int ccl = second ? c - G->C0 : c;
         const int nt = second ? G->ntiles1 : G->ntiles0, Cs = second ? G->C1 : G->C0;
         const float* p = (second ? G->part1 : G->part0) + ((size_t)(unsigned)b * (unsigned)nt * (unsigned)Cs + (unsigned)ccl) * 2;
+        // (the channel's affine parameters and FiLM entries are requested first: their latency passes behind the partial sums)
+        const float gam = G->gamma[c], bet = G->beta[c];
+        float ffa = 0.f, ffb = 0.f;
+        if (G->film) {
+          const float* f = G->film + (size_t)(unsigned)b * G->film_stride + G->film_off;
+          ffa = f[c];
+          ffb = f[G->Ctot + c];
+        }
         double s1 = 0.0, s2 = 0.0;
         unsigned bad = 0;
         for (int t0 = j; t0 < nt; t0 += 8 * tpc) {
@@ -736,13 +750,12 @@ __global__ __launch_bounds__((ws_threads<T, ROWS>())) void conv_ws_kernel(const 
         double var = s2 * G->inv_count - mean * mean;
         if (var < 0.0) var = 0.0;
         const double rstd = 1.0 / sqrt(var + 1e-5);
-        double scale = rstd * (double)G->gamma[c];
-        double shift = (double)G->beta[c] - mean * scale;
+        double scale = rstd * (double)gam;
+        double shift = (double)bet - mean * scale;
         if (G->film) {
-          const float* f = G->film + (size_t)(unsigned)b * G->film_stride + G->film_off;
-          const double fa = (double)f[c] + 1.0;
+          const double fa = (double)ffa + 1.0;
           scale *= fa;
-          shift = shift * fa + (double)f[G->Ctot + c];
+          shift = shift * fa + (double)ffb;
         }
         if (j == 0) *reinterpret_cast<float2*>(tab + c * 8) = float2{(float)scale, (float)shift};
       }
@@ -775,7 +788,18 @@ __global__ __launch_bounds__((ws_threads<T, ROWS>())) void conv_ws_kernel(const 
     TileCo pt_{0, 0, 0};
     bool pending = false;
     int obuf = 0, pbuf = 0;  // (DB) buffer the next epilogue writes / the pending tile sits in
-    auto store_tile = [&]() {
+    // store_tile(i0, i1): pieces [i0, i1) of the pending out-tile's NIT row-pair pieces leave for global memory; piece 0 carries the
+    // tile statistics.  All pieces go at the end of the successor's FIRST step.  -DVQVS_WS_SPREAD=1 spreads them over the successor's
+    // steps 0 .. n - 2 (all before the barrier in front of its last chunk, whose epilogue rewrites the out-tile), `st_per` pieces per
+    // step: built and parity-clean in round 5 on the hypothesis that the store (~1-2 us of consumer work in one step) makes that
+    // step wait -- measured 67.75 against 67.9 clips/s (same-box A/B): it does not; what the stores cost is not their burstiness
+    // (DESIGN.md section 7, round 5).
+#ifndef VQVS_WS_SPREAD
+#define VQVS_WS_SPREAD 0
+#endif
+    constexpr int NIT = (X3 || WPE) ? 1 : (ROWS / 2) / (NPT / (CT / 8));
+    const int st_per = (VQVS_WS_SPREAD && n > 1) ? (NIT + (n - 1) - 1) / (n - 1) : NIT;
+    auto store_tile = [&](int i0, int i1) {
       int zl = 0;
       asm volatile("" : "+v"(zl));  // (keeps the per-lane address arithmetic of this rare block out of the loop's live registers)
       const int ltid = tid + zl;
@@ -783,7 +807,7 @@ __global__ __launch_bounds__((ws_threads<T, ROWS>())) void conv_ws_kernel(const 
       const int nvalid = min(a.TTO, a.Lout - t0);
       const int co0 = pt_.ty * CT;
       (void)nvalid;
-      if (a.stats != nullptr && ltid < CT) {
+      if (i0 == 0 && a.stats != nullptr && ltid < CT) {
         const float2* const red = reinterpret_cast<const float2*>(smem + R_OFF + pbuf * R_BYTES);
         float t1 = 0.f, t2 = 0.f;
 #pragma unroll
@@ -806,11 +830,15 @@ __global__ __launch_bounds__((ws_threads<T, ROWS>())) void conv_ws_kernel(const 
       const char* const lsrc = smem + O_OFF + pbuf * O_BYTES + p0 * OP + col * 32;
       // buffer stores through a descriptor that ends behind the tile's last valid row (the clip's end, or where the next tile's
       // rows begin): rows past it are dropped by the address check -- no per-row branches
-      const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(outp + (size_t)pt_.b * a.Lout * a.Cout, 0,
-                                                                            (t0 + nvalid) * a.Cout * 2, 0x00020000);
-      const int vo = ((t0 + 2 * p0) * a.Cout + co0 + col * 8) * 2;
+      // (ablation bit 16384: every tile is stored over the clip's first rows -- the same store instructions, but the bytes stay in L2)
+      const int t0s = (VQVS_WS_EXP & 16384) ? 0 : t0;
+      const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(outp + (size_t)((VQVS_WS_EXP & 16384) ? 0 : pt_.b) * a.Lout * a.Cout, 0,
+                                                                            (t0s + nvalid) * a.Cout * 2, 0x00020000);
+      const int vo = ((t0s + 2 * p0) * a.Cout + co0 + col * 8) * 2;
+      static_assert(X3 || WPE || NIT == (ROWS / 2) / PSTEP, "pieces per tile");
 #pragma unroll
       for (int i = 0; i < (ROWS / 2) / PSTEP; ++i) {
+        if (i < i0 || i >= i1) continue;  // (wave-uniform)
         const u32x4 lo = *reinterpret_cast<const u32x4*>(lsrc + i * PSTEP * OP);
         const u32x4 hi = *reinterpret_cast<const u32x4*>(lsrc + i * PSTEP * OP + 16);
         u32x4 e, o;
@@ -926,8 +954,9 @@ __global__ __launch_bounds__((ws_threads<T, ROWS>())) void conv_ws_kernel(const 
           gn_clip = ct.b;
           if (reaches(ct.b + gn_ahead)) gn_table(ct.b + gn_ahead);
         }
+        WS_TMARK(6)
         if ((n == 1 || (VQVS_WS_EXP & 256)) && pending) {  // (one-chunk tiles: the previous tile leaves here, from the other buffer)
-          store_tile();
+          store_tile(0, NIT);
           pending = false;
         }
         if (ct.ty != bias_ty) {  // (one channel tile per launch at Cout <= 128: loaded once, at start-up)
@@ -1226,10 +1255,11 @@ __global__ __launch_bounds__((ws_threads<T, ROWS>())) void conv_ws_kernel(const 
       // The previous tile's rows leave at the END of its successor's first step, behind the wait for this step's weight DMA: the
       // stores then have a whole step to be acknowledged before the next vmcnt(0) (CDNA counts stores in vmcnt too, and a wait
       // placed right after them exposes the full write latency once per tile).
-      if (n > 1 && pending && cci == 1) {
+      if (n > 1 && pending && cci >= 1) {  // (cci - 1 = the successor's step that just ended: 0 .. n - 2)
         if constexpr (!RES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!(VQVS_WS_EXP & 4)) store_tile();
-        pending = false;
+        const int i0 = (cci - 1) * st_per, i1 = i0 + st_per;
+        if (!(VQVS_WS_EXP & 4) && i0 < NIT) store_tile(i0, i1 < NIT ? i1 : NIT);
+        if (i1 >= NIT) pending = false;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (!(VQVS_WS_EXP & 32768)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -1238,11 +1268,11 @@ __global__ __launch_bounds__((ws_threads<T, ROWS>())) void conv_ws_kernel(const 
       }
       WS_TMARK(4)
     }
-    if (pending) store_tile();
+    if (pending) store_tile(0, NIT);
 #ifdef VQVS_TIMING
-    WS_TMARK(0)
+    WS_TMARK(5)
     if (lane == 0 && ((int)blockIdx.x & 15) == 3) {
-      for (int i = 0; i < 5; ++i) atomicAdd(&g_ws_timing[8 + i], tacc[i]);
+      for (int i = 0; i < 7; ++i) atomicAdd(&g_ws_timing[8 + i], tacc[i]);  // (5: the last tile's store, 6: look-ahead GroupNorm tables)
       atomicAdd(&g_ws_timing[22], t_su1 - t_sh0);  // startup of the sampled consumer wave: entry -> requests out and tables built,
       atomicAdd(&g_ws_timing[23], t_su2 - t_su1);  // -> first barrier passed,
       atomicAdd(&g_ws_timing[24], t_su3 - t_su2);  // -> first weights landed,

@@ -157,6 +157,18 @@ __global__ __launch_bounds__(256) void gn_prepare_kernel(const GnArgs a) {
   const int c_lo = blockIdx.y * ng * gs;            // first channel owned
   const int cw_tot = ng * gs;                       // channels owned
   const int C0 = a.src[0].C;
+  // this thread's affine parameters and FiLM row entries (used at the very end) are requested now, so that their latency passes
+  // behind the reduction instead of adding a second round trip to global memory after it (cw_tot <= 256: one channel per thread)
+  float pg = 0.f, pb = 0.f, pfa = 0.f, pfb = 0.f;
+  if (tid < cw_tot) {
+    pg = a.gamma[c_lo + tid];
+    pb = a.beta[c_lo + tid];
+    if (a.film) {
+      const float* f = a.film + (size_t)b * a.film_stride + a.film_off;
+      pfa = f[c_lo + tid];
+      pfb = f[a.Ctot + c_lo + tid];
+    }
+  }
   for (int c0 = 0; c0 < cw_tot; c0 += 256) {
     const int cw = min(256, cw_tot - c0);
     const int nsl = 256 / cw;  // tile slices per channel
@@ -224,12 +236,13 @@ __global__ __launch_bounds__(256) void gn_prepare_kernel(const GnArgs a) {
   for (int i = tid; i < cw_tot; i += 256) {
     const int c = c_lo + i;
     const int g = i / gs;
-    double scale = grstd[g] * (double)a.gamma[c];
-    double shift = (double)a.beta[c] - gmean[g] * scale;
+    const bool pre = i == tid;  // (always, while cw_tot <= 256; a wider share falls back to loading here)
+    double scale = grstd[g] * (double)(pre ? pg : a.gamma[c]);
+    double shift = (double)(pre ? pb : a.beta[c]) - gmean[g] * scale;
     if (a.film) {
       const float* f = a.film + (size_t)b * a.film_stride + a.film_off;
-      const double fa = (double)f[c] + 1.0;
-      const double fb = (double)f[a.Ctot + c];
+      const double fa = (double)(pre ? pfa : f[c]) + 1.0;
+      const double fb = (double)(pre ? pfb : f[a.Ctot + c]);
       scale *= fa;
       shift = shift * fa + fb;
     }
