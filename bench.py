@@ -20,7 +20,11 @@ the gate (2.6e-3); fp32 (3-term split MFMA) is the 5e-6 parity mode.
 
 Rank 0 prints ONE JSON line.  Extra objects:
   roofline     - the dominant kernel (fused MFMA conv): algorithmic bytes of all its launches in one
-                 forward / their summed duration, measured live with hipEvents on the launch stream.
+                 forward / their summed duration, measured live with hipEvents on the launch stream
+                 (per-launch brackets minus the measured bracket overhead = the launches back to back, what
+                 rocprofv3 --kernel-trace --stats reports under profiles/; the bracketed figure is kept beside it).
+                 `traffic` / `mfma_busy` come from rocprofv3 --pmc passes and are replayed from profiles/latest_pmc_*
+                 only when that summary is stamped with the build id of the library loaded here.
   cpu_baseline - the CPU oracle (oracle/ref_cpu.py, stock torch fp32 on the host cores) on a bounded
                  sample of the same workload, extrapolated to 50 steps.  Reported baseline, not the target.
 """
