@@ -134,6 +134,9 @@ struct IterGeom {
   const void* avg_src;        // avg-pool path: the thread's octet of row 0, chunk 0
   int Csrc, c0;
   int wbase, wstep;           // byte offset of chunk 0 in the packed weights, bytes per chunk
+  int aff2;                   // two-tensor affine prologue (SegDesc.src2): rows of `clip2` at the same offsets, coefficients at `cfp`
+  const void* clip2;
+  const float4* cfp;          // (P, Q, R, 0) of the thread's octet in chunk 0
 };
 
 // DMA (all segments raw bf16, i.e. inputs already transformed by xform_kernel or untransformed skip-conv inputs): the
@@ -143,8 +146,11 @@ struct IterGeom {
 // address side when loading and on the LDS address side when reading.
 // BWF: the epilogue can multiply by gelu'(u) (fused GELU backward of the guidance schedule).  A template flag, not a run-time
 // branch: carried by every forward convolution the extra epilogue code measured +1.5...2 % (21.5 -> 21.9 ms per forward).
-template <typename T, bool X3, int WN, int HALO, bool SKIPV, int WGN, int WM, bool DMA, bool BWF>
+// AFF2: a segment may carry the two-tensor affine prologue of the guidance backward (kernels.hpp SegDesc.src2): template flag for the
+// same reason as BWF -- its second set of prefetch registers and coefficient loads must not weigh on any other launch.
+template <typename T, bool X3, int WN, int HALO, bool SKIPV, int WGN, int WM, bool DMA, bool BWF, bool AFF2 = false>
 __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs a) {
+  static_assert(!AFF2 || (!DMA && !SKIPV), "the two-tensor prologue stages through registers and has no identity skip");
   constexpr int TT = 4 * WM * 32;  // staged rows: 4 waves along time x WM MFMA tiles of 32 rows
   constexpr int NTH = 256 * WGN;  // 4 waves along time x WGN waves along output channels
   constexpr int NPF = (TT * 4) / NTH;  // prefetched (row, octet) items per thread: exactly the 256 staged rows x 4 octets
@@ -259,11 +265,29 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
     g.c0 = sg.c0;
     g.wbase = (int)(sg.w_off * 2);
     g.wstep = g.ntaps * a.Cout * 32 * 2;
+    g.aff2 = 0;
+    g.clip2 = nullptr;
+    g.cfp = nullptr;
+    if constexpr (AFF2) {
+      const void* s2 = s == 0 ? a.seg[0].src2 : (s == 1 ? a.seg[1].src2 : a.seg[2].src2);
+      if (s2 != nullptr) {
+        const float4* cf = s == 0 ? a.seg[0].coef : (s == 1 ? a.seg[1].coef : a.seg[2].coef);
+        const int cst = s == 0 ? a.seg[0].coef_stride : (s == 1 ? a.seg[1].coef_stride : a.seg[2].coef_stride);
+        const int cc0 = s == 0 ? a.seg[0].coef_c0 : (s == 1 ? a.seg[1].coef_c0 : a.seg[2].coef_c0);
+        g.aff2 = 1;
+        g.clip2 = reinterpret_cast<const T*>(s2) + (size_t)b * sg.Lsrc * sg.Csrc;
+        g.cfp = cf + (size_t)b * cst + cc0 + oct * 8;
+      }
+    }
     return g;
   };
 
   // ---- prefetch registers -------------------------------------------------------------
   Raw8<T> ra[NPF];
+  Raw8<T> ra2[AFF2 ? NPF : 1];  // AFF2: the second tensor's rows
+  f32x4 rcf[AFF2 ? 8 : 1];      // AFF2: (P, Q, R, 0) of the thread's eight channels
+  (void)ra2;
+  (void)rcf;
   f32x4 rss[4];
   u32x4 rwh[NWV], rwl[NWV];
   (void)rwl;
@@ -280,6 +304,16 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
       const int base = g.base_off + g.ch * (32 * (int)sizeof(T));
 #pragma unroll
       for (int i = 0; i < NPF; ++i) ra[i].load(rs, base + i * g.step);
+      if constexpr (AFF2) {
+        if (g.aff2) {
+          const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.clip2), 0, g.clip_bytes, 0x00020000);
+#pragma unroll
+          for (int i = 0; i < NPF; ++i) ra2[i].load(rs2, base + i * g.step);
+          const float4* cp = g.cfp + g.ch * 32;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) rcf[j] = *reinterpret_cast<const f32x4*>(cp + j);
+        }
+      }
     }
     TMARK(12)
     const int wbase = g.wbase + g.ch * g.wstep;
@@ -335,7 +369,26 @@ __global__ __launch_bounds__(256 * WGN, 2) void conv_mfma_kernel(const ConvArgs 
         sc[2 * j] = rss[j][0]; sh[2 * j] = rss[j][1]; sc[2 * j + 1] = rss[j][2]; sh[2 * j + 1] = rss[j][3];
       }
     }
-    if (!g.avg && g.nrows >= TT && (g.xform || !X3)) {
+    if (AFF2 && g.aff2) {
+      // d h = P * du + Q * h + R per (clip, channel) (GroupNorm backward), then the rows outside the clip back to the convolution's
+      // zero padding (their loads returned zeros, the affine made them R).  Host side: 3-tap segment, whole 256-row window.
+      if constexpr (AFF2) {
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+          f32x8 v = ra[i].get();
+          const f32x8 x = ra2[i].get();
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = fmaf(rcf[j][0], v[j], fmaf(rcf[j][1], x[j], rcf[j][2]));
+          put_row<X3, V8>(act_hi, act_lo, act_lds[i], v);
+        }
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+          const int r = (tid >> 2) + (NTH / 4) * i;
+          const int tm = g.base_time + r;
+          if (r >= g.nrows || tm < 0 || tm >= g.row_bound) put_row<X3, V8>(act_hi, act_lo, act_lds[i], f32x8_zero());
+        }
+      }
+    } else if (!g.avg && g.nrows >= TT && (g.xform || !X3)) {
       // fast path (the usual 3-tap segment): every staged item is a row of this segment and the whole wave takes the same
       // branch, so the four items run as straight-line code -- no per-item exec masks, one uniform branch instead of four
       // (measured -0.7 % convolution time)
@@ -677,7 +730,7 @@ constexpr int lds_bytes() {
   return stage > ost ? stage : ost;
 }
 
-template <typename T, bool X3, int WN, int HALO, bool SKIPV, int WGN, int WM, bool DMA, bool BWF>
+template <typename T, bool X3, int WN, int HALO, bool SKIPV, int WGN, int WM, bool DMA, bool BWF, bool AFF2 = false>
 int launch_o(const ConvArgs& a, int B, hipStream_t st) {
   constexpr int LDS = lds_bytes<X3, WN, HALO, WGN, WM>();
   static_assert(LDS <= 160 * 1024, "LDS budget");
@@ -685,12 +738,12 @@ int launch_o(const ConvArgs& a, int B, hipStream_t st) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   if (!attr_done[dev].load(std::memory_order_acquire)) {
-    VQVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<T, X3, WN, HALO, SKIPV, WGN, WM, DMA, BWF>),
+    VQVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<T, X3, WN, HALO, SKIPV, WGN, WM, DMA, BWF, AFF2>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_done[dev].store(true, std::memory_order_release);
   }
   dim3 grid((a.Lout + a.tile_rows - 1) / a.tile_rows, a.Cout / (WGN * WN * 32), B);
-  hipLaunchKernelGGL((conv_mfma_kernel<T, X3, WN, HALO, SKIPV, WGN, WM, DMA, BWF>), grid, dim3(256 * WGN), LDS, st, a);
+  hipLaunchKernelGGL((conv_mfma_kernel<T, X3, WN, HALO, SKIPV, WGN, WM, DMA, BWF, AFF2>), grid, dim3(256 * WGN), LDS, st, a);
   VQVS_HIP(hipGetLastError());
   return 0;
 }
@@ -698,6 +751,16 @@ int launch_o(const ConvArgs& a, int B, hipStream_t st) {
 template <typename T, bool X3, int WN, int HALO, bool SKIPV, int WGN = 1, int WM = 2, bool DMA = false>
 int launch_t(const ConvArgs& a, int B, hipStream_t st) {
   if constexpr (!SKIPV) {  // (transposed convolutions have no identity skip)
+    bool aff2 = false;
+    for (int s = 0; s < a.nseg; ++s) aff2 = aff2 || a.seg[s].src2 != nullptr;
+    if (aff2) {  // two-tensor affine prologue (guidance backward, conv1^T of a block): register staging, small halo
+      if constexpr (!DMA && HALO == 4) {
+        if (a.nbw) return launch_o<T, X3, WN, HALO, SKIPV, WGN, WM, DMA, true, true>(a, B, st);
+        return launch_o<T, X3, WN, HALO, SKIPV, WGN, WM, DMA, false, true>(a, B, st);
+      } else {
+        VQVS_FAIL(-1, "conv: the two-tensor prologue is built for register-staged launches of dilation <= 2");
+      }
+    }
     if (a.nbw) return launch_o<T, X3, WN, HALO, SKIPV, WGN, WM, DMA, true>(a, B, st);
   } else {
     if (a.nbw) VQVS_FAIL(-1, "conv: the fused GELU backward is not built for identity-skip launches");
@@ -711,7 +774,7 @@ int launch_p(const ConvArgs& a, int B, hipStream_t st, bool wide, bool big_halo,
     // 128-channel output tiles (8 waves): the prologue and the activation reads are shared by twice as many channels
     if (a.Cout % 128 == 0) {
       bool raw = true;  // every segment untransformed and unresized-or-upsampled: stage by LDS-DMA
-      for (int s = 0; s < a.nseg; ++s) raw = raw && a.seg[s].ss == nullptr && a.seg[s].resize != RESIZE_AVG2;
+      for (int s = 0; s < a.nseg; ++s) raw = raw && a.seg[s].ss == nullptr && a.seg[s].resize != RESIZE_AVG2 && a.seg[s].src2 == nullptr;
       // (measured on the 512-channel launches: -3...-5 % for plain, -10...-14 % with 1x1 skip-conv segments,
       //  +4...+7 % with an identity skip, which therefore keeps the register path)
       if (raw && a.skip == nullptr && dma_enabled()) {
@@ -784,6 +847,8 @@ int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st) {
     if (g.C % 32 != 0 || (g.ntaps != 1 && g.ntaps != 3) || g.dil > 32 || g.dil < 1)
       VQVS_FAIL(-1, "conv: unsupported segment C=%d taps=%d dil=%d", g.C, g.ntaps, g.dil);
     if (g.resize == RESIZE_UP2 && g.ntaps == 3 && g.dil != 1) VQVS_FAIL(-1, "conv: upsample needs dilation 1");
+    if (g.src2 != nullptr && (g.ss != nullptr || g.resize != RESIZE_NONE || g.ntaps != 3 || g.dil > 2 || a.skip != nullptr || g.coef == nullptr))
+      VQVS_FAIL(-1, "conv: the two-tensor prologue needs a plain 3-tap segment of dilation <= 2 without identity skip");
     if (g.ntaps == 3 && g.dil > dmax) dmax = g.dil;
   }
   const bool wide = (a.Cout % 64) == 0;

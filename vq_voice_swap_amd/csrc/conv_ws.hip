@@ -1452,7 +1452,7 @@ bool ws_plan(const ConvArgs& a, int B, int precision, WsPlan& plan) {
   int dmax = 0, n = 0;
   for (int s = 0; s < a.nseg; ++s) {
     const SegDesc& g = a.seg[s];
-    if (g.C % 32 != 0 || (g.ntaps != 1 && g.ntaps != 3) || !len_ok(g.resize, g.Lsrc)) return 0;
+    if (g.C % 32 != 0 || (g.ntaps != 1 && g.ntaps != 3) || !len_ok(g.resize, g.Lsrc) || g.src2 != nullptr) return 0;  // (src2: conv_mfma_kernel's two-tensor prologue)
     if ((long long)g.Lsrc * g.Csrc * es >= (1LL << 29)) return 0;  // (the dummy loads of an AVG launch rely on offset + 2^30 being out of range)
     avg = avg || g.resize == RESIZE_AVG2;
     WsSeg& q = w.seg[s];

@@ -44,6 +44,14 @@ struct SegDesc {
   int dil;
   int resize;        // RESIZE_*
   int ss_stride, ss_c0;
+  // Two-tensor affine prologue (guidance backward only, conv_mfma_kernel's AFF2 form): when `src2` is set the staged row is
+  //   coef.x * src + coef.y * src2 + coef.z      per (clip, channel),
+  // i.e. GroupNorm's backward  d h = P * du + Q * h + R  (backward_kernels.hip gn_bw / bw_affine) evaluated while the NEXT transposed
+  // convolution stages its input, instead of a streaming pass that writes d h and a convolution that reads it back.  `src2` has the
+  // shape and channel window of `src`; no (scale, shift), no resize.
+  const void* src2;
+  const float4* coef;  // [B][coef_stride] (P, Q, R, 0), this segment's channels start at coef_c0
+  int coef_stride, coef_c0;
 };
 
 // Fused GELU backward in the epilogue of a transposed convolution (the guidance backward schedule, backward_kernels.hip

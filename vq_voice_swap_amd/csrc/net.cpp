@@ -406,6 +406,10 @@ class Builder {
     size_t ss_off;
     int ss_stride, ss_c0;
     long long w_off;
+    // two-tensor affine prologue (kernels.hpp SegDesc.src2): staged row = P * t + Q * t2 + R with (P, Q, R, 0) rows at coef_off (misc region)
+    bool aff2 = false;
+    TensorH t2{};
+    size_t coef_off = 0;
   };
 
   // GELU backward fused into a transposed convolution's epilogue (kernels.hpp BwActFuse): forward tensors covering the output
@@ -447,6 +451,7 @@ class Builder {
     int kchunks = skip ? 2 : 0;  // (K chunks of 32 channels per tile: a one-chunk tile is only covered at 32 output channels)
     for (auto& g : segs) kchunks += g.C / 32;
     bool ws_ok = !out.f32 && !epi_gelu && fuse == nullptr && out_lshift == -1000 && kchunks >= 2;
+    for (auto& g : segs) ws_ok = ws_ok && !g.aff2;  // (conv_mfma_kernel's two-tensor prologue)
     if (m_->cfg.precision == VQVS_PREC_F32) {
       // fp32 storage: a tile geometry other than the default one may only be chosen where conv_ws_kernel is certain to take the
       // launch (conv_mfma_kernel has one geometry): its fp32 form has no avg-pooled sources, wants 32-channel chunks, and
@@ -465,7 +470,7 @@ class Builder {
     double ktot = 0;
     double conv_elems = 0, conv_f32 = 0;
     for (auto& s : segs) {
-      conv_elems += s.C * lscale(s.t.lshift);
+      conv_elems += s.C * lscale(s.t.lshift) * (s.aff2 ? 2 : 1);
       ktot += (double)s.C * s.ntaps;
     }
     if (skip) conv_elems += K.C * lscale(K.lshift);
@@ -497,6 +502,12 @@ class Builder {
         g.resize = S[i].resize;
         g.ss_stride = S[i].ss_stride;
         g.ss_c0 = S[i].ss_c0;
+        if (S[i].aff2) {
+          g.src2 = self->act(S[i].t2.off);
+          g.coef = reinterpret_cast<const float4*>(self->miscp(S[i].coef_off));
+          g.coef_stride = S[i].C;
+          g.coef_c0 = 0;
+        }
       }
       a.w_hi = reinterpret_cast<const bf16_t*>(self->wp(hi_off));
       a.w_lo = x3 ? reinterpret_cast<const bf16_t*>(self->wp(lo_off)) : nullptr;
@@ -740,11 +751,18 @@ class Builder {
     });
   }
   // plain convolution of a raw tensor with transposed weights (no prologue, no statistics, zero bias)
+  // aff_xf / aff_coef: the source is read through the two-tensor affine prologue P * src + Q * aff_xf + R (GroupNorm's backward folded
+  // into this convolution's staging instead of a bw_affine pass in front of it)
   int add_conv_t(const TensorH& src, const float* W, int Cout_fwd, int Cin_fwd, int ktaps, int dil, const TensorH& out,
-                 const BwFuse* fuse = nullptr) {
+                 const BwFuse* fuse = nullptr, const TensorH* aff_xf = nullptr, size_t aff_coef = 0) {
     const std::vector<float> Wt = transpose_flip(W, Cout_fwd, Cin_fwd, ktaps);
     PackedConv pk(m_->cfg.precision);
     SegSpec g{src, 0, Cout_fwd, ktaps, dil, RESIZE_NONE, false, 0, 0, 0, 0};
+    if (aff_xf) {
+      g.aff2 = true;
+      g.t2 = *aff_xf;
+      g.coef_off = aff_coef;
+    }
     g.w_off = pk.append(Wt.data(), Cin_fwd, Cout_fwd, ktaps, 0, Cout_fwd);
     return add_conv({g}, pk, std::vector<float>(Cin_fwd, 0.f), Cin_fwd, out, nullptr, 0, -1000, false, fuse);
   }
@@ -770,14 +788,17 @@ class Builder {
     const int tr2 = add_conv_t(dout, P(c2 + ".weight"), cout, cout, 3, s.dil, t1, fuse ? &f2 : nullptr);
     if (!fuse) add_bw_act(t1, BW_SAME, r.h1, r.ss2, t1, pa);
     const size_t cf2 = add_gn_bw(cout, out_shift, pa, r.ss2, r.mr2, fuse ? tr2 : STAT_TILE);
-    add_bw_affine(t1, r.h1, cf2, nullptr, BW_SAME, nullptr, t1);
+    // d h1 = P * du2 + Q * h1 + R: evaluated by conv1^T while it stages its input (kernels.hpp SegDesc.src2) instead of a streaming
+    // pass that writes d h1 and a convolution that reads it back.  VQVS_BW_AFF2=0: the separate bw_affine launch (A/B measurements).
+    static const bool aff2 = getenv("VQVS_BW_AFF2") ? atoi(getenv("VQVS_BW_AFF2")) != 0 : true;
+    if (!aff2) add_bw_affine(t1, r.h1, cf2, nullptr, BW_SAME, nullptr, t1);
     // d resize(gelu1) = conv1^T(d h1);  du1 = resize^T(.) * gelu'(u1);  dx = GN1 backward + skip path
     TensorH t2 = new_tensor(cin, out_shift, false, false);
     const size_t pb = alloc_stats(cin, in_shift);
     const bool fuse1 = fuse && rs == BW_SAME;  // (resizing blocks keep the separate kernel: their gradient changes resolution first)
     BwFuse f1{{r.x}, r.ss1, cin, pb};
     if (cat) f1.xf.push_back(r.x2);
-    const int tr1 = add_conv_t(t1, P(pre + "pre_cond.2.weight"), cout, cin, 3, 1, t2, fuse1 ? &f1 : nullptr);
+    const int tr1 = add_conv_t(t1, P(pre + "pre_cond.2.weight"), cout, cin, 3, 1, t2, fuse1 ? &f1 : nullptr, aff2 ? &r.h1 : nullptr, cf2);
     release(t1);
     if (!cat) {
       TensorH du1 = rs != BW_SAME ? new_tensor(cin, in_shift, false, false) : t2;
