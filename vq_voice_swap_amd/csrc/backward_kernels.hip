@@ -100,16 +100,29 @@ __global__ __launch_bounds__(256) void gn_bw_kernel(const GnBwArgs a) {
   const int b = blockIdx.x;
   const int gs = a.C / a.groups;
   const float* p = a.partials + (size_t)b * a.ntiles * a.C * 2;
+  // (this thread's first forward coefficients, used at the very end, are requested before the reduction)
+  const float2 ss_pre = tid < a.C ? a.ss[(size_t)b * a.C + tid] : float2{0.f, 0.f};
+  const float2 mr_pre = tid < a.C ? a.mr[(size_t)b * a.C + tid] : float2{0.f, 0.f};
   for (int c0 = 0; c0 < a.C; c0 += 256) {
     const int cw = min(256, a.C - c0);
     const int nsl = 256 / cw;
     const int c = c0 + tid % cw, sl = tid / cw;
     if (sl < nsl) {
       double s1 = 0.0, s2 = 0.0;
-      for (int t = sl; t < a.ntiles; t += nsl) {
-        const float2 q = *reinterpret_cast<const float2*>(p + ((size_t)t * a.C + c) * 2);
-        s1 += (double)q.x;
-        s2 += (double)q.y;
+      // eight independent loads in flight per thread (as gn_prepare_kernel: one load per iteration made this a chain of memory
+      // latencies, 32 deep at the top level); the additions keep their order
+      for (int t0 = sl; t0 < a.ntiles; t0 += 8 * nsl) {
+        float2 q[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int t = t0 + k * nsl;
+          q[k] = t < a.ntiles ? *reinterpret_cast<const float2*>(p + ((size_t)t * a.C + c) * 2) : float2{0.f, 0.f};
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          s1 += (double)q[k].x;
+          s2 += (double)q[k].y;
+        }
       }
       part[tid * 2] = s1;
       part[tid * 2 + 1] = s2;
@@ -145,8 +158,9 @@ __global__ __launch_bounds__(256) void gn_bw_kernel(const GnBwArgs a) {
   __syncthreads();
   for (int c = tid; c < a.C; c += 256) {
     const int g = c / gs;
-    const double mean = (double)mr[c].x, rstd = (double)mr[c].y;
-    const double P = (double)ss[c].x;
+    const float2 mrc = c == tid ? mr_pre : mr[c], ssc = c == tid ? ss_pre : ss[c];
+    const double mean = (double)mrc.x, rstd = (double)mrc.y;
+    const double P = (double)ssc.x;
     const double Q = -rstd * rstd * gB[g];
     const double R = -rstd * gA[g] - Q * mean;
     a.coef[(size_t)b * a.C + c] = make_float4((float)P, (float)Q, (float)R, 0.f);

@@ -1546,7 +1546,9 @@ bool ws_plan(const ConvArgs& a, int B, int precision, WsPlan& plan) {
   static const int gn_env = getenv("VQVS_WS_GN") ? atoi(getenv("VQVS_WS_GN")) : 1;  // 0: always the gn_prepare launch (A/B measurements)
   // (clips of up to 8 tiles: measured +0.6 % clips/s; from 16 tiles on the table's construction costs what its gn_prepare launch
   //  did -- 66.19 / 66.08 / 66.01 clips/s at 16 / 32 / 64 against 66.16 at 8, 67.1 against 67.5 with every launch fused)
-  static const int gn_max_tiles = getenv("VQVS_WS_GN_TILES") ? atoi(getenv("VQVS_WS_GN_TILES")) : 8;
+  // (round 5: with the table's parameter loads hoisted in front of its partial sums, 16 / 32 tiles measure 67.80 / 67.88 clips/s against
+  //  67.66 at 8 and 67.73 at 64, two alternating rounds on one box: 32, i.e. clips of up to 8064 rows)
+  static const int gn_max_tiles = getenv("VQVS_WS_GN_TILES") ? atoi(getenv("VQVS_WS_GN_TILES")) : 32;
   if (a.gn != nullptr && gn_env) {
     const GnArgs& g = *a.gn;
     const int cpg = g.groups > 0 ? g.Ctot / g.groups : 0;
