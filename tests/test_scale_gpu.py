@@ -304,3 +304,25 @@ def test_resblock_many_clips_long_launch_seeded_sweep(dev):
             got = m(x.to(dev), None if e is None else e.to(dev)).cpu()
             err = rel_rms(got, want) if got.shape == want.shape else float("inf")
             assert err < tol, (prec, dict(cin=cin, cout=cout, scale=scale, dil=dil, emb=emb, L=L, B=B), err)
+
+
+def test_one_step_clips_many_per_workgroup(dev):
+    """32 x 3 -> 32 at L <= 254 is ONE K chunk per clip: a persistent workgroup then walks one clip per step, the producers' load
+    cursor runs four clips ahead of the clip being staged, and the (scale, shift) ring must hold all of them (a ring
+    of 4 was overwritten from ~1024 clips on).  1500 and 2600 clips (6 and 10 per workgroup), with and without FiLM."""
+    from vq_voice_swap_amd.unet import ResBlockModule
+
+    for i, (B, L, emb, dil) in enumerate([(1500, 200, None, 1), (2600, 96, 128, 2)]):
+        m = ResBlockModule(32, emb, None, 1.0, dil)
+        det_init_((f"ring{i}." + k, v) for k, v in m.block.state_dict().items())
+        x = seeded((B, 32, L), 8000 + i)
+        e = seeded((B, emb), 8100 + i) if emb else None
+        sd = {"b." + k: v.detach() for k, v in m.block.state_dict().items()}
+        want = ref_cpu.res_block(x, sd, "b", dict(cin=32, cout=32, scale=1.0, dil=dil), e)
+        for prec, tol in (("fp32", 2e-4), ("fp16", 4e-3)):
+            m.set_precision(prec)
+            got = m(x.to(dev), None if e is None else e.to(dev)).cpu()
+            err = rel_rms(got, want)
+            # per clip too: a wrong table for ONE clip must not hide in the batch's RMS
+            per_clip = ((got - want).pow(2).mean(dim=(1, 2)).sqrt() / want.pow(2).mean(dim=(1, 2)).sqrt()).max().item()
+            assert err < tol and per_clip < 5 * tol, (prec, B, L, err, per_clip)
