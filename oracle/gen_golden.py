@@ -622,6 +622,30 @@ def gen_custom_topologies():
     save("f14_custom_topologies", **out)
 
 
+# ---------------------------------------------------------------- F15: classifiers of non-default topology (classifier.py:52-58)
+def gen_custom_classifiers():
+    import torch.nn.functional as F
+    from vq_voice_swap.models import Classifier  # reference
+
+    out = {}
+    for tag, kw, T in (("c_a", dict(channel_mult=(1, 2, 2, 4), output_mult=8, depth_mult=1), 4096),
+                       ("c_b", dict(channel_mult=(1, 1, 2, 2, 2, 4), output_mult=4, depth_mult=3), 8192)):
+        clf = Classifier(num_labels=5, base_channels=32, **kw)
+        det_init_(("clf." + tag + "." + k, v) for k, v in clf.state_dict().items())
+        clf.eval()
+        sd = state_of(clf)
+        x, ts, labels = seeded((2, 1, T), 900 + len(out)), torch.tensor([0.3, 0.75]), torch.tensor([4, 0])
+        xg = x.clone().requires_grad_()
+        logits = clf(xg, ts)
+        grad = torch.autograd.grad(F.log_softmax(logits, dim=-1)[range(2), labels].sum(), xg)[0]
+        topo = dict(channel_mult=kw["channel_mult"], depth_mult=kw["depth_mult"])
+        check("custom classifier logits " + tag, logits.detach(), ref_cpu.classifier(sd, 32, x, ts, topology=topo), tol=1e-6)
+        check("custom classifier grad " + tag, grad, ref_cpu.classifier_cond_fn(sd, 32, labels, topology=topo)(x, ts), tol=1e-6)
+        out[tag + ".x"], out[tag + ".ts"], out[tag + ".labels"], out[tag + ".logits"], out[tag + ".grad"] = x, ts, labels, logits.detach(), grad
+        print(f"  {tag}: {kw} logits rms={logits.pow(2).mean().sqrt().item():.4f} grad rms={grad.pow(2).mean().sqrt().item():.3e}")
+    save("f15_custom_classifiers", **out)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     if not only or "resblocks" in only:
@@ -650,6 +674,8 @@ if __name__ == "__main__":
         gen_conv_mfcc_stack()
     if not only or "topology" in only:
         gen_custom_topologies()
+    if not only or "classifier_topology" in only:
+        gen_custom_classifiers()
     if "unet64" in only:  # (minutes of CPU time: only on request; the committed fixture is re-verifiable with this argument)
         gen_sampler_unet64()
     if "guided64" in only:  # (BASELINE config 5 at 100 steps: about a minute of CPU time, on request)

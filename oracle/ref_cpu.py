@@ -209,8 +209,10 @@ def unet_encoder(sd: State, base: int, x: Tensor, prefix: str = "encoder", topol
     return F.conv1d(h, sd[p + ".out.1.weight"], sd[p + ".out.1.bias"], padding=1)
 
 
-def classifier(sd: State, base: int, x: Tensor, ts: Tensor, prefix: str = "") -> Tensor:
-    """Classifier.forward (models/classifier.py:31-36, 111-121, 153-158, 170-191): logits [N, num_labels]."""
+def classifier(sd: State, base: int, x: Tensor, ts: Tensor, prefix: str = "", topology: Optional[dict] = None) -> Tensor:
+    """Classifier.forward (models/classifier.py:31-36, 111-121, 153-158, 170-191): logits [N, num_labels].  `topology` =
+    dict(channel_mult=, depth_mult=) for a stem other than the default one (classifier.py:52-58; output_mult is read off the weights)."""
+    CHANNEL_MULT, DEPTH_MULT = (tuple(topology["channel_mult"]), topology["depth_mult"]) if topology else (globals()["CHANNEL_MULT"], globals()["DEPTH_MULT"])  # noqa: N806
     p = prefix + "stem"
     emb = time_embedding(ts, sd, p + ".time_embed")
     emb = F.linear(F.gelu(emb), sd[p + ".time_embed_extra.1.weight"], sd[p + ".time_embed_extra.1.bias"])
@@ -238,13 +240,13 @@ def classifier(sd: State, base: int, x: Tensor, ts: Tensor, prefix: str = "") ->
     return F.linear(F.gelu(feat), sd[prefix + "out.1.weight"], sd[prefix + "out.1.bias"])
 
 
-def classifier_cond_fn(sd: State, base: int, labels: Tensor, scale: float = 1.0) -> Callable:
+def classifier_cond_fn(sd: State, base: int, labels: Tensor, scale: float = 1.0, topology: Optional[dict] = None) -> Callable:
     """sample_diffusion.py:34-42."""
 
     def cond_fn(x, ts):
         with torch.enable_grad():
             xg = x.detach().clone().requires_grad_()
-            logp = F.log_softmax(classifier(sd, base, xg, ts), dim=-1)
+            logp = F.log_softmax(classifier(sd, base, xg, ts, topology=topology), dim=-1)
             grads = torch.autograd.grad(logp[range(len(xg)), labels].sum(), xg)[0]
         return grads.detach() * scale
 

@@ -59,6 +59,43 @@ def test_native_classifier_vs_golden(golden, precision, tol_logit, tol_grad):
     assert torch.equal(clf.log_prob_grad(x, ts, labels, 1.0), grad)
 
 
+CUSTOM = [("c_a", dict(channel_mult=(1, 2, 2, 4), output_mult=8, depth_mult=1), 4096),
+          ("c_b", dict(channel_mult=(1, 1, 2, 2, 2, 4), output_mult=4, depth_mult=3), 8192)]
+
+
+def test_custom_classifier_topology_param_table(lib_built):
+    """classifier.py:52-58: any channel_mult / output_mult / depth_mult -- the library's parameter table is the module's state dict."""
+    from vq_voice_swap_amd import _native
+
+    for tag, kw, T in CUSTOM:
+        clf = Classifier(num_labels=5, base_channels=32, **kw)
+        sd = clf.state_dict()
+        table = _native.param_table(clf._cfg())
+        assert len(table) == len(sd) and set(n for n, _ in table) == set(sd.keys()), tag
+        assert all(tuple(sd[n].shape) == s for n, s in table)
+        assert clf.downsample_rate == 2 ** len(kw["channel_mult"]) and clf.save_kwargs()["output_mult"] == kw["output_mult"]
+    assert Classifier(num_labels=5, base_channels=32)._cfg().topology_set == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,tol_logit,tol_grad", [("fp32", 2e-4, 2e-3), ("fp16", 8e-3, 3e-2)])
+def test_custom_classifier_topology_vs_reference_fixture(golden, precision, tol_logit, tol_grad):
+    """F15: classifiers of non-default topology built by the reference's own constructor: logits and d log p(y|x)/dx."""
+    z = golden("f15_custom_classifiers")
+    dev = torch.device("cuda:0")
+    for tag, kw, T in CUSTOM:
+        clf = Classifier(num_labels=5, base_channels=32, **kw)
+        det_init_(("clf." + tag + "." + k, v) for k, v in clf.state_dict().items())
+        clf.eval().to(dev)
+        clf.set_precision(precision)
+        x, ts, labels = (torch.from_numpy(z[f"{tag}.{k}"]).to(dev) for k in ("x", "ts", "labels"))
+        grad, logits = clf.log_prob_grad(x, ts, labels, 1.0, return_logits=True)
+        assert rel_rms(logits.cpu(), torch.from_numpy(z[tag + ".logits"])) < tol_logit, (tag, precision)
+        assert rel_rms(grad.cpu(), torch.from_numpy(z[tag + ".grad"])) < tol_grad, (tag, precision, rel_rms(grad.cpu(), torch.from_numpy(z[tag + ".grad"])))
+        with pytest.raises(ValueError, match="downsample rate"):
+            clf(torch.zeros(1, 1, clf.downsample_rate * 3 + 2, device=dev), torch.zeros(1, device=dev))
+
+
 @pytest.mark.gpu
 def test_native_classifier_shapes_and_errors():
     dev = torch.device("cuda:0")

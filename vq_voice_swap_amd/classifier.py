@@ -24,7 +24,7 @@ import torch.nn as nn
 
 from .base import Savable
 from . import _native
-from .unet import CHANNEL_MULT, ResBlock, _NativeModule, _groups, _scaled, _seq
+from .unet import CHANNEL_MULT, ResBlock, _NativeModule, _groups, _scaled, _seq, check_base_channels, check_topology
 
 
 class AttentionPool1d(nn.Module):
@@ -63,8 +63,10 @@ class Classifier(_NativeModule, Savable):
         super().__init__()
         self.num_labels = num_labels
         self.stem = ClassifierStem(**kwargs)
-        if tuple(self.stem.channel_mult) != CHANNEL_MULT or self.stem.depth_mult != 2 or self.stem.output_mult != 16:
-            raise ValueError("the gfx950 library implements the reference's default classifier topology only")
+        check_base_channels(self.stem.base_channels)
+        check_topology(self.stem.base_channels, self.stem.channel_mult, self.stem.depth_mult, ())  # (classifier.py:52-58: any of these)
+        if int(self.stem.output_mult) != self.stem.output_mult or not 1 <= self.stem.output_mult * self.stem.base_channels <= 4096:
+            raise ValueError(f"output_mult={self.stem.output_mult}: the feature width must be in 1..4096")
         self.out = _seq(None, _scaled(nn.Linear(self.stem.out_channels, num_labels), 0.0))
 
     def save_kwargs(self) -> Dict[str, Any]:
@@ -82,6 +84,9 @@ class Classifier(_NativeModule, Savable):
         cfg.base_channels = self.stem.base_channels
         cfg.in_channels = 1
         cfg.num_labels = self.num_labels
+        if (tuple(self.stem.channel_mult), self.stem.depth_mult) != (CHANNEL_MULT, 2):
+            cfg.set_topology(self.stem.channel_mult, self.stem.depth_mult, ())
+        cfg.reserved[1] = 0 if self.stem.output_mult == 16 else int(self.stem.output_mult)
         return cfg
 
     def _prepare(self, x: torch.Tensor, ts: torch.Tensor):

@@ -134,7 +134,8 @@ static int check_run(vqvs_model* m, int kind, int B, int L) {
   if (m->cfg.kind != kind) VQVS_FAIL(VQVS_ERR_STATE, "handle kind %d used as kind %d", m->cfg.kind, kind);
   if (B < 1 || B > m->cfg.max_batch) VQVS_FAIL(VQVS_ERR_ARG, "batch %d outside 1..%d", B, m->cfg.max_batch);
   if (L < 1 || L > m->cfg.max_T) VQVS_FAIL(VQVS_ERR_ARG, "length %d outside 1..%d", L, m->cfg.max_T);
-  if (kind == VQVS_KIND_CLASSIFIER && (L % 512)) VQVS_FAIL(VQVS_ERR_ARG, "T=%d is not a multiple of the classifier downsample rate 512", L);
+  if (kind == VQVS_KIND_CLASSIFIER && (L % (2 * unet_rate(m->cfg))))  // (the stem halves the length after EVERY level: 2^levels, classifier.py:79-96)
+    VQVS_FAIL(VQVS_ERR_ARG, "T=%d is not a multiple of the classifier downsample rate %d", L, 2 * unet_rate(m->cfg));
   if (kind != VQVS_KIND_RESBLOCK && kind != VQVS_KIND_MFCC_ENCODER && (L % unet_rate(m->cfg)))
     VQVS_FAIL(VQVS_ERR_ARG, "T=%d is not a multiple of the UNet downsample rate %d", L, unet_rate(m->cfg));
   if (kind == VQVS_KIND_RESBLOCK && m->cfg.rb_resize == RESIZE_AVG2 && (L % 2)) VQVS_FAIL(VQVS_ERR_ARG, "avg-pool resblock needs even L");

@@ -29,7 +29,7 @@ struct Topo {
 };
 Topo topo_of(const vqvs_cfg& c) {
   Topo t;
-  const bool custom = c.topology_set != 0 && (c.kind == VQVS_KIND_PREDICTOR || c.kind == VQVS_KIND_ENCODER);
+  const bool custom = c.topology_set != 0 && (c.kind == VQVS_KIND_PREDICTOR || c.kind == VQVS_KIND_ENCODER || c.kind == VQVS_KIND_CLASSIFIER);
   if (custom) {
     t.mult.assign(c.channel_mult, c.channel_mult + std::max(0, std::min(c.n_levels, (int)VQVS_MAX_LEVELS)));
     t.depth = c.depth_mult;
@@ -37,7 +37,7 @@ Topo topo_of(const vqvs_cfg& c) {
   } else {
     t.mult = {1, 1, 2, 2, 2, 4, 4, 8, 8};  // unet.py:20
     t.depth = 2;                            // unet.py:22
-    if (c.kind != VQVS_KIND_ENCODER) t.dil = {4, 8, 16, 32};  // unet.py:21 (UNetEncoder: out_dilations = (), unet.py:192)
+    if (c.kind != VQVS_KIND_ENCODER && c.kind != VQVS_KIND_CLASSIFIER) t.dil = {4, 8, 16, 32};  // unet.py:21 (UNetEncoder: out_dilations = (), unet.py:192)
   }
   return t;
 }
@@ -93,8 +93,9 @@ int encoder_blocks(int base, const Topo& tp, std::vector<BlockSpec>& blocks) {  
 }
 
 // ClassifierStem (classifier.py:79-96): like the encoder, but FiLM-conditioned and with a x0.5 block after EVERY level
-void classifier_blocks(int base, std::vector<BlockSpec>& blocks) {
-  const Topo tp = topo_of(vqvs_cfg{});  // (classifier.py:52-58: the same defaults)
+// (classifier.py:52-58: channel_mult and depth_mult with the UNets' defaults; output_mult = vqvs_cfg.reserved[1], 0 = 16.)  Returns the
+// width of the last block.
+int classifier_blocks(int base, const Topo& tp, std::vector<BlockSpec>& blocks) {
   const int NLEVEL = tp.levels(), DEPTH_MULT = tp.depth;
   int cur = base;
   for (int depth = 0; depth < NLEVEL; ++depth) {
@@ -105,7 +106,9 @@ void classifier_blocks(int base, std::vector<BlockSpec>& blocks) {
     }
     blocks.push_back({"stem.blocks." + std::to_string(blocks.size()), cur, cur, RESIZE_AVG2, 2, false});
   }
+  return cur;
 }
+int classifier_output_mult(const vqvs_cfg& c) { return c.reserved[1] > 0 ? c.reserved[1] : 16; }
 
 void block_params(std::vector<ParamDef>& out, const std::string& p, const BlockSpec& s, int emb, bool dropout) {
   const std::string pre = p.empty() ? "" : p + ".";
@@ -912,8 +915,8 @@ int gn_groups(int ch) {  // unet.py:345-349
 }
 
 static int check_topology(const vqvs_cfg& c) {
-  if (c.topology_set && c.kind != VQVS_KIND_PREDICTOR && c.kind != VQVS_KIND_ENCODER)
-    VQVS_FAIL(VQVS_ERR_ARG, "a custom topology is built for predictor and encoder handles only (kind %d)", c.kind);
+  if (c.topology_set && c.kind != VQVS_KIND_PREDICTOR && c.kind != VQVS_KIND_ENCODER && c.kind != VQVS_KIND_CLASSIFIER)
+    VQVS_FAIL(VQVS_ERR_ARG, "a custom topology is built for predictor, encoder and classifier handles only (kind %d)", c.kind);
   if (c.topology_set) {
     if (c.n_levels < 1 || c.n_levels > VQVS_MAX_LEVELS) VQVS_FAIL(VQVS_ERR_ARG, "n_levels must be in 1..%d (got %d)", VQVS_MAX_LEVELS, c.n_levels);
     for (int i = 0; i < c.n_levels; ++i)
@@ -973,15 +976,15 @@ int enumerate_params(const vqvs_cfg& c, std::vector<ParamDef>& out) {
     BlockSpec s{"", c.rb_cin, c.rb_cout, c.rb_resize, c.rb_dilation, false};
     block_params(out, "", s, c.rb_emb_channels, drop);
   } else if (c.kind == VQVS_KIND_CLASSIFIER) {  // classifier.py:18-104, 131-150
-    const int E = 4 * base, cur = 8 * base, F = 16 * base;
+    const int E = 4 * base, F = classifier_output_mult(c) * base;
+    std::vector<BlockSpec> blocks;
+    const int cur = classifier_blocks(base, topo_of(c), blocks);
     out.push_back({"stem.time_embed.proj.weight", {E, E}});
     out.push_back({"stem.time_embed.proj.bias", {E}});
     out.push_back({"stem.time_embed_extra.1.weight", {E, E}});
     out.push_back({"stem.time_embed_extra.1.bias", {E}});
     out.push_back({"stem.in_conv.weight", {base, 1, 3}});
     out.push_back({"stem.in_conv.bias", {base}});
-    std::vector<BlockSpec> blocks;
-    classifier_blocks(base, blocks);
     for (auto& s : blocks) block_params(out, s.prefix, s, E, false);
     out.push_back({"stem.out.0.0.weight", {cur}});
     out.push_back({"stem.out.0.0.bias", {cur}});
@@ -1058,7 +1061,9 @@ static int check_cfg(const vqvs_cfg& c) {
     if (c.reserved[1] < 1 || c.max_T % c.reserved[1]) VQVS_FAIL(VQVS_ERR_ARG, "downsample_rate %d must divide max_T", c.reserved[1]);
   } else if (c.kind == VQVS_KIND_CLASSIFIER) {
     if (c.num_labels < 1 || c.num_labels > 8192) VQVS_FAIL(VQVS_ERR_ARG, "classifier num_labels must be in 1..8192 (got %d)", c.num_labels);
-    if (c.max_T % 512) VQVS_FAIL(VQVS_ERR_ARG, "classifier max_T must be a multiple of 512 (got %d)", c.max_T);
+    if (c.max_T % (2 * unet_rate(c))) VQVS_FAIL(VQVS_ERR_ARG, "classifier max_T must be a multiple of %d (got %d)", 2 * unet_rate(c), c.max_T);
+    if (c.reserved[1] < 0 || c.reserved[1] * c.base_channels > 4096) VQVS_FAIL(VQVS_ERR_ARG, "classifier output_mult (reserved[1]) out of range (got %d)", c.reserved[1]);
+    if (c.topology_set && c.n_dilations != 0) VQVS_FAIL(VQVS_ERR_ARG, "the classifier stem has no dilation list");
   } else {
     if (c.out_channels % 32 || c.out_channels < 32) VQVS_FAIL(VQVS_ERR_ARG, "encoder out_channels must be a multiple of 32");
   }
@@ -1361,9 +1366,9 @@ int build_model(vqvs_model* m, const float* const* hp) {
     }
   } else if (c.kind == VQVS_KIND_CLASSIFIER) {
     // Classifier.forward (classifier.py:31-36, 111-121) + the input gradient used by cond_fn (sample_diffusion.py:34-42)
-    const int E = 4 * base, cur = 8 * base, F = 16 * base, NL = c.num_labels;
+    const int E = 4 * base, F = classifier_output_mult(c) * base, NL = c.num_labels;
     std::vector<BlockSpec> blocks;
-    classifier_blocks(base, blocks);
+    const int cur = classifier_blocks(base, topo_of(c), blocks);
     b.persist = true;  // the backward pass re-reads every block input, h1 and their GroupNorm coefficients
     std::vector<float> freqs(E / 2);
     for (int i = 0; i < E / 2; ++i)
