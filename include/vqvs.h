@@ -42,7 +42,8 @@ extern "C" {
 #define VQVS_KIND_PREDICTOR 0 /* UNetPredictor  (reference vq_voice_swap/models/unet.py:16-184) */
 #define VQVS_KIND_ENCODER 1   /* UNetEncoder    (reference unet.py:187-245) */
 #define VQVS_KIND_RESBLOCK 2  /* one ResBlock   (reference unet.py:248-316); unit-test granularity */
-#define VQVS_KIND_CLASSIFIER 3 /* Classifier   (reference vq_voice_swap/models/classifier.py:18-191), base_channels + num_labels */
+#define VQVS_KIND_CLASSIFIER 3 /* Classifier   (reference vq_voice_swap/models/classifier.py:18-191), base_channels + num_labels;
+                                  reserved[1] = output_mult (0 = 16); topology_set = 1: channel_mult / depth_mult (n_dilations = 0) */
 #define VQVS_KIND_ENCPRED 4    /* EncoderPredictor (reference models/encoder_predictor.py:14-75): base_channels, out_channels =
                                   bottleneck_dim, reserved[1] = downsample_rate, reserved[2] = num_latents */
 
@@ -74,8 +75,8 @@ typedef struct vqvs_cfg {
   /* VQVS_KIND_RESBLOCK only: */
   int32_t rb_cin, rb_cout, rb_resize /*0 none, 1 avg-pool/2, 2 nearest x2*/, rb_dilation, rb_emb_channels /*0 = no FiLM*/;
   int32_t reserved[5];
-  /* Topology of VQVS_KIND_PREDICTOR / VQVS_KIND_ENCODER (reference UNetPredictor.__init__ unet.py:17-30, UNetEncoder.__init__
-   * unet.py:188-196).  topology_set = 0: the reference's defaults -- channel_mult (1,1,2,2,2,4,4,8,8), depth_mult 2,
+  /* Topology of VQVS_KIND_PREDICTOR / VQVS_KIND_ENCODER / VQVS_KIND_CLASSIFIER (reference UNetPredictor.__init__ unet.py:17-30,
+   * UNetEncoder.__init__ unet.py:188-196, ClassifierStem.__init__ classifier.py:52-58).  topology_set = 0: the reference's defaults -- channel_mult (1,1,2,2,2,4,4,8,8), depth_mult 2,
    * middle_dilations (4,8,16,32) / out_dilations () -- and the fields below are ignored.  topology_set = 1: they describe the
    * network: n_levels = len(channel_mult) in 1..VQVS_MAX_LEVELS, every channel_mult[i] * base_channels a multiple of 32 and at most
    * 1024; depth_mult in 1..8; n_dilations = len(middle_dilations) (predictor) or len(out_dilations) (encoder), 0 allowed, each
