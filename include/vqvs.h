@@ -64,7 +64,7 @@ typedef struct vqvs_model vqvs_model;
 typedef struct vqvs_cfg {
   int32_t kind;          /* VQVS_KIND_* */
   int32_t base_channels; /* multiple of 32 (reference configs: 32, 64) */
-  int32_t in_channels;   /* must be 1 (reference default, unet.py:25) */
+  int32_t in_channels;   /* 1 (the reference's default and every caller's value, unet.py:25) .. 64; predictor / encoder handles only */
   int32_t out_channels;  /* predictor: 1 or a multiple of 32; encoder: multiple of 32 */
   int32_t cond_channels; /* 0 = unconditional (unet.py:46-47) */
   int32_t num_labels;    /* 0 = no class embedding (unet.py:44-45) */
@@ -110,7 +110,7 @@ int64_t vqvs_model_device_bytes(const vqvs_model* m);
 
 /* ---- UNet forward -----------------------------------------------------------
  * eps = UNetPredictor.forward(x, ts, cond=, labels=)   reference unet.py:118-163
- *   d_x     [B,1,T] f32      d_ts [B] f32
+ *   d_x     [B,in_channels,T] f32      d_ts [B] f32
  *   d_cond  [B,cond_channels,T1] f32 or NULL (must match cfg, unet.py:126-131); T1 = T/256 (cfg.reserved[3] = 0: cond from a
  *           UNet encoder), (T/160 + 1 - 2)/2 + 1 = T/320 (reserved[3] = 1: cond from the MFCC encoder), or ANY length L
  *           (reserved[3] = 1000 + L: the handle then expects exactly L rows per clip, for every T); it is added to the
@@ -122,7 +122,7 @@ int vqvs_unet_forward(vqvs_model* m, const float* d_x, const float* d_ts, const 
                       const int64_t* d_labels, float* d_out, int B, int T, void* stream);
 
 /* z = UNetEncoder.forward(x)   reference unet.py:229-241
- *   d_x [B,1,T] f32 -> d_z [B,out_channels,T/256] f32 (NCT) */
+ *   d_x [B,in_channels,T] f32 -> d_z [B,out_channels,T/downsample_rate] f32 (NCT) */
 int vqvs_encoder_forward(vqvs_model* m, const float* d_x, float* d_z, int B, int T, void* stream);
 
 /* z = ConvMFCCEncoder.forward(x)   reference models/conv_encoder.py:90-110 (VQVS_KIND_MFCC_ENCODER handles):

@@ -145,6 +145,33 @@ def test_open_topology_vs_reference_fixture(golden, dev):
         assert got.shape == want.shape and rel_rms(got, want) < FP32_REL, (tag, rel_rms(got, want))
 
 
+def test_multi_channel_input_vs_oracle(dev):
+    """in_channels > 1 (unet.py:25, 193: the reference's constructors take it; every caller uses 1): predictor with 3 input channels
+    and 2 output channels... the output head keeps its own width; encoder with 2 input channels -- against the oracle."""
+    from vq_voice_swap_amd import UNetEncoder, UNetPredictor
+
+    m = UNetPredictor(32, channel_mult=(1, 2, 2), middle_dilations=(2,), depth_mult=1, in_channels=3)
+    det_init_(("predictor.mc." + k, v) for k, v in m.state_dict().items())
+    m.eval()
+    sd = {"predictor." + k: v.detach().clone() for k, v in m.state_dict().items()}
+    x, ts = seeded((2, 3, 1024), 91), torch.tensor([0.25, 0.6])
+    want = ref_cpu.unet_predictor(sd, 32, x, ts, topology=dict(channel_mult=(1, 2, 2), middle_dilations=(2,), depth_mult=1))
+    for prec, tol in (("fp32", FP32_REL), ("fp16", FP16_REL)):
+        m.set_precision(prec)
+        got = m(x.to(dev), ts.to(dev)).cpu()
+        assert got.shape == want.shape == (2, 1, 1024) and rel_rms(got, want) < tol, (prec, rel_rms(got, want))
+    with pytest.raises(ValueError, match="expected x of shape"):
+        m(torch.zeros(2, 1, 1024, device=dev), ts.to(dev))
+    e = UNetEncoder(32, channel_mult=(1, 2), depth_mult=1, in_channels=2, out_channels=64)
+    det_init_(("encoder.mc." + k, v) for k, v in e.state_dict().items())
+    e.eval()
+    sde = {"encoder." + k: v.detach().clone() for k, v in e.state_dict().items()}
+    xe = seeded((3, 2, 512), 92, 0.3)
+    wante = ref_cpu.unet_encoder(sde, 32, xe, topology=dict(channel_mult=(1, 2), out_dilations=(), depth_mult=1))
+    gote = e(xe.to(dev)).cpu()
+    assert gote.shape == wante.shape and rel_rms(gote, wante) < FP32_REL
+
+
 def test_whole_clip_tiles_for_wide_dilations_vs_oracle(dev):
     """The middle blocks' shapes (unet.py:21, 78-88: dilation 4 .. 32 at 250 rows, 256 / 512 channels): a clip of at most 255 rows is
     one zero-padded tile of conv_ws_kernel whatever the dilation (template flag ZP) -- every dilation, clip lengths around the limits

@@ -107,9 +107,10 @@ int conv_tile_rows(int dmax, int Cout, int precision, bool ws_ok = false);
 // ----------------------------------------------------------------------------------
 // small kernels
 // ----------------------------------------------------------------------------------
-struct InConvArgs {  // Conv1d(1 -> C, k=3, pad=1) (+ nearest-upsampled cond projection), unet.py:137-139
-  const float* x;    // [B][T]
-  const float* w;    // [C][3]
+struct InConvArgs {  // Conv1d(Cin -> C, k=3, pad=1) (+ nearest-upsampled cond projection), unet.py:49, 137-139
+  const float* x;    // [B][Cin][T] (the boundary's NCT layout; Cin = 1 for every caller of the reference)
+  const float* w;    // [C][Cin][3]
+  int Cin;           // 0 is read as 1
   const float* bias; // [C]
   const void* condp; // [B][cond_len][C] of T or nullptr: added as F.interpolate(cond, T) (nearest), unet.py:139
   int cond_len;      // rows of condp per clip (T/256 behind a UNet encoder, T/320 behind the MFCC encoder)

@@ -26,14 +26,15 @@ __global__ __launch_bounds__(256) void in_conv_kernel(const InConvArgs a) {
   const int r0 = tid / opr;
   const int c = oct * 8;
   float w0[8], w1[8], w2[8], bs[8];
+  const int Cin = a.Cin > 0 ? a.Cin : 1;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    w0[j] = a.w[(c + j) * 3 + 0];
-    w1[j] = a.w[(c + j) * 3 + 1];
-    w2[j] = a.w[(c + j) * 3 + 2];
+  for (int j = 0; j < 8; ++j) {  // input channel 0 in registers (the only one, for every caller of the reference)
+    w0[j] = a.w[(c + j) * Cin * 3 + 0];
+    w1[j] = a.w[(c + j) * Cin * 3 + 1];
+    w2[j] = a.w[(c + j) * Cin * 3 + 2];
     bs[j] = a.bias[c + j];
   }
-  const float* xb = a.x + (size_t)b * a.T;
+  const float* xb = a.x + (size_t)b * Cin * a.T;
   f32x8 s1 = f32x8_zero(), s2 = f32x8_zero();
   const bool active = r0 < rpp && oct < opr;
   // nearest-neighbour source row exactly as PyTorch's upsample_nearest1d computes it: min(floor(dst * (float)in / out), in - 1)
@@ -48,6 +49,15 @@ __global__ __launch_bounds__(256) void in_conv_kernel(const InConvArgs a) {
       f32x8 v;
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = fmaf(w2[j], xp, fmaf(w1[j], x0, fmaf(w0[j], xm, bs[j])));
+      for (int ci = 1; ci < Cin; ++ci) {  // further input channels (unet.py:25 allows them): weights from L1, in channel order
+        const float* xc = xb + (size_t)ci * a.T;
+        const float ym = t > 0 ? xc[t - 1] : 0.f, y0 = xc[t], yp = t + 1 < a.T ? xc[t + 1] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float* wc = a.w + ((c + j) * Cin + ci) * 3;
+          v[j] = fmaf(wc[2], yp, fmaf(wc[1], y0, fmaf(wc[0], ym, v[j])));
+        }
+      }
       if (a.condp) {
         const int cr = min((int)floorf((float)t * cond_scale), a.cond_len - 1);
         const T* cp = reinterpret_cast<const T*>(a.condp) + ((size_t)b * a.cond_len + cr) * a.C + c;

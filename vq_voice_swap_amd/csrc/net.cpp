@@ -1032,7 +1032,10 @@ static int check_cfg(const vqvs_cfg& c) {
   // C / 8 row pieces over a 256-thread workgroup; every convolution works on 32-channel K chunks)
   if (c.base_channels != 32 && c.base_channels != 64 && c.base_channels != 128)
     VQVS_FAIL(VQVS_ERR_ARG, "base_channels must be 32, 64 or 128 (got %d)", c.base_channels);
-  if (c.in_channels != 1) VQVS_FAIL(VQVS_ERR_ARG, "in_channels must be 1 (got %d)", c.in_channels);
+  if (c.in_channels < 1 || c.in_channels > 64) VQVS_FAIL(VQVS_ERR_ARG, "in_channels must be in 1..64 (got %d)", c.in_channels);
+  if (c.in_channels != 1 && c.kind != VQVS_KIND_PREDICTOR && c.kind != VQVS_KIND_ENCODER)
+    VQVS_FAIL(VQVS_ERR_ARG, "in_channels = %d: only predictor and encoder handles take more than one input channel (the classifier stem and the "
+                            "encoder predictor are mono in the reference too, classifier.py:73, encoder_predictor.py:40)", c.in_channels);
   if (c.kind == VQVS_KIND_MFCC_ENCODER) {
     if (c.precision != VQVS_PREC_F32) VQVS_FAIL(VQVS_ERR_ARG, "the MFCC encoder feeds the VQ layer (bit-exact indices): fp32 precision only");
     if (c.reserved[1] != 1 && c.reserved[1] != 2) VQVS_FAIL(VQVS_ERR_ARG, "ConvMFCCEncoder version must be 1 or 2 (got %d)", c.reserved[1]);
@@ -1076,6 +1079,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
   if (int e = enumerate_params(c, m->params)) return e;
   const int prec = c.precision;
   const int base = c.base_channels;
+  const int in_ch = c.in_channels;
   // NOTE: the builder object must outlive the ops (lambdas capture it for pointer resolution).
   auto keep = std::make_shared<Builder>(m, hp);
   m->keepalive = keep;
@@ -1206,10 +1210,11 @@ int build_model(vqvs_model* m, const float* const* hp) {
     {
       const size_t w = b.blob_f32(px + "in_conv.weight"), bi = b.blob_f32(px + "in_conv.bias");
       const TensorH cp = condp;
-      m->meta.push_back({"in_conv", "1->" + std::to_string(base), base + (has_cond ? base * lscale(condp.lshift) : 0.0), 4.0, 0});
+      m->meta.push_back({"in_conv", std::to_string(in_ch) + "->" + std::to_string(base), base + (has_cond ? base * lscale(condp.lshift) : 0.0), 4.0 * in_ch, 0});
       m->add_op([=](const RunCtx& r) -> int {
         InConvArgs a{};
         a.x = r.x;
+        a.Cin = in_ch;
         a.w = reinterpret_cast<const float*>(bp->wp(w));
         a.bias = reinterpret_cast<const float*>(bp->wp(bi));
         a.condp = has_cond ? bp->act(cp.off) : nullptr;
@@ -1666,6 +1671,7 @@ int build_model(vqvs_model* m, const float* const* hp) {
       m->add_op([=](const RunCtx& r) -> int {
         InConvArgs a{};
         a.x = r.x;
+        a.Cin = in_ch;
         a.w = reinterpret_cast<const float*>(bp->wp(w));
         a.bias = reinterpret_cast<const float*>(bp->wp(bi));
         a.condp = nullptr;
