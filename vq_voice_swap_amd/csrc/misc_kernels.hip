@@ -14,7 +14,8 @@ namespace {
 // One thread = one time row x 8 channels; a workgroup = 256 rows = one statistics tile.
 // Pure write-bound: 4 B read, C*sizeof(T) B written per row.
 // ------------------------------------------------------------------------------------
-template <typename T>
+// MC: more than one input channel (a template flag: the mono kernel, which every caller of the reference runs, stays as it was)
+template <typename T, bool MC>
 __global__ __launch_bounds__(256) void in_conv_kernel(const InConvArgs a) {
   __shared__ float red[256 * 8 * 2];
   const int tid = threadIdx.x;
@@ -26,7 +27,7 @@ __global__ __launch_bounds__(256) void in_conv_kernel(const InConvArgs a) {
   const int r0 = tid / opr;
   const int c = oct * 8;
   float w0[8], w1[8], w2[8], bs[8];
-  const int Cin = a.Cin > 0 ? a.Cin : 1;
+  const int Cin = MC ? a.Cin : 1;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {  // input channel 0 in registers (the only one, for every caller of the reference)
     w0[j] = a.w[(c + j) * Cin * 3 + 0];
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(256) void in_conv_kernel(const InConvArgs a) {
       f32x8 v;
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = fmaf(w2[j], xp, fmaf(w1[j], x0, fmaf(w0[j], xm, bs[j])));
+      if constexpr (MC)
       for (int ci = 1; ci < Cin; ++ci) {  // further input channels (unet.py:25 allows them): weights from L1, in channel order
         const float* xc = xb + (size_t)ci * a.T;
         const float ym = t > 0 ? xc[t - 1] : 0.f, y0 = xc[t], yp = t + 1 < a.T ? xc[t + 1] : 0.f;
@@ -478,7 +480,11 @@ __global__ __launch_bounds__(256) void ntc_stats_kernel(const T* in, float* stat
 int launch_in_conv(const InConvArgs& a, int B, int precision, hipStream_t st) {
   if (a.C % 8 || a.C > 256 || (256 % (a.C / 8)) != 0) VQVS_FAIL(-1, "in_conv: unsupported C=%d", a.C);
   dim3 grid((a.T + STAT_TILE - 1) / STAT_TILE, B);
-  VQVS_BY_PRECISION(precision, hipLaunchKernelGGL(in_conv_kernel<T>, grid, dim3(256), 0, st, a));
+  if (a.Cin > 1) {
+    VQVS_BY_PRECISION(precision, hipLaunchKernelGGL((in_conv_kernel<T, true>), grid, dim3(256), 0, st, a));
+  } else {
+    VQVS_BY_PRECISION(precision, hipLaunchKernelGGL((in_conv_kernel<T, false>), grid, dim3(256), 0, st, a));
+  }
   VQVS_HIP(hipGetLastError());
   return 0;
 }
