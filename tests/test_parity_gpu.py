@@ -145,6 +145,35 @@ def test_open_topology_vs_reference_fixture(golden, dev):
         assert got.shape == want.shape and rel_rms(got, want) < FP32_REL, (tag, rel_rms(got, want))
 
 
+def test_unusual_widths_vs_oracle(dev):
+    """The reference takes any base_channels (unet.py:17-30): widths other than the tuned 32 / 64 / 128 -- 96 (GroupNorm groups of 3
+    channels, 32-channel tiles, a 12-octet row in in_conv / out_conv) and 160 -- run generic forms of a few kernels: predictor (with
+    labels) and encoder against the oracle."""
+    from vq_voice_swap_amd import UNetEncoder, UNetPredictor
+
+    topo = dict(channel_mult=(1, 2, 4), middle_dilations=(3,), depth_mult=1)
+    for base, T in ((96, 2048), (160, 1024)):
+        m = UNetPredictor(base, num_labels=3, **topo)
+        det_init_((f"predictor.w{base}." + k, v) for k, v in m.state_dict().items())
+        m.eval()
+        sd = {"predictor." + k: v.detach().clone() for k, v in m.state_dict().items()}
+        x, ts, labels = seeded((2, 1, T), 95 + base), torch.tensor([0.2, 0.7]), torch.tensor([2, 0])
+        want = ref_cpu.unet_predictor(sd, base, x, ts, labels=labels, topology=topo)
+        for prec, tol in (("fp32", FP32_REL), ("fp16", FP16_REL)):
+            m.set_precision(prec)
+            got = m(x.to(dev), ts.to(dev), labels=labels.to(dev)).cpu()
+            assert rel_rms(got, want) < tol, (base, prec, rel_rms(got, want))
+    e = UNetEncoder(96, channel_mult=(1, 2), depth_mult=2, out_channels=96)
+    det_init_(("encoder.w96." + k, v) for k, v in e.state_dict().items())
+    e.eval()
+    sde = {"encoder." + k: v.detach().clone() for k, v in e.state_dict().items()}
+    xe = seeded((2, 1, 1024), 97, 0.3)
+    wante = ref_cpu.unet_encoder(sde, 96, xe, topology=dict(channel_mult=(1, 2), out_dilations=(), depth_mult=2))
+    assert rel_rms(e(xe.to(dev)).cpu(), wante) < FP32_REL
+    with pytest.raises(ValueError, match="multiples of 32"):
+        UNetPredictor(48)
+
+
 def test_multi_channel_input_vs_oracle(dev):
     """in_channels > 1 (unet.py:25, 193: the reference's constructors take it; every caller uses 1): predictor with 3 input channels
     and 2 output channels... the output head keeps its own width; encoder with 2 input channels -- against the oracle."""

@@ -151,6 +151,43 @@ __global__ __launch_bounds__(256) void out_conv_kernel(const OutConvArgs a) {
   if (t < a.L) a.out[(size_t)b * a.L + t] = a.bias + y[0][tid] + y[1][tid + 1] + y[2][tid + 2];
 }
 
+// out_conv for widths whose octet count is not a power of two (base_channels 96, 160, ...: the shuffle reduction above needs a row's
+// lanes to be a power-of-two group inside one wave): one thread = one row, all channels; same arithmetic per element, the channel
+// sum in channel order.  A fallback for unusual widths, not a tuned kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void out_conv_rows_kernel(const OutConvArgs a) {
+  constexpr int GQ = GeluQ<T>::q;
+  __shared__ float y[3][STAT_TILE + 2];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * STAT_TILE;
+  const float2* ss = a.ss + (size_t)b * a.C;
+  for (int r = tid; r < STAT_TILE + 2; r += 256) {
+    const int t = t0 - 1 + r;
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+    if (t >= 0 && t < a.L) {
+      const T* xr = reinterpret_cast<const T*>(a.in) + ((size_t)b * a.L + t) * a.C;
+      for (int c = 0; c < a.C; c += 8) {
+        const f32x8 v = Elem<T>::load8(xr + c);
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          const float2 q0 = ss[c + j], q1 = ss[c + j + 1];
+          const f32x2 g = gelu2<GQ>(fma2(f32x2{v[j], v[j + 1]}, f32x2{q0.x, q1.x}, f32x2{q0.y, q1.y}));
+          p0 = fmaf(a.w[0 * a.C + c + j + 1], g[1], fmaf(a.w[0 * a.C + c + j], g[0], p0));
+          p1 = fmaf(a.w[1 * a.C + c + j + 1], g[1], fmaf(a.w[1 * a.C + c + j], g[0], p1));
+          p2 = fmaf(a.w[2 * a.C + c + j + 1], g[1], fmaf(a.w[2 * a.C + c + j], g[0], p2));
+        }
+      }
+    }
+    y[0][r] = p0;
+    y[1][r] = p1;
+    y[2][r] = p2;
+  }
+  __syncthreads();
+  const int t = t0 + tid;
+  if (t < a.L) a.out[(size_t)b * a.L + t] = a.bias + y[0][tid] + y[1][tid + 1] + y[2][tid + 2];
+}
+
 // ------------------------------------------------------------------------------------
 // GroupNorm (+FiLM) coefficients.  One workgroup per clip.  Tile partials are summed in a
 // fixed order in fp64, so the result does not depend on scheduling.
@@ -478,7 +515,7 @@ __global__ __launch_bounds__(256) void ntc_stats_kernel(const T* in, float* stat
 }  // namespace
 
 int launch_in_conv(const InConvArgs& a, int B, int precision, hipStream_t st) {
-  if (a.C % 8 || a.C > 256 || (256 % (a.C / 8)) != 0) VQVS_FAIL(-1, "in_conv: unsupported C=%d", a.C);
+  if (a.C % 8 || a.C > 256) VQVS_FAIL(-1, "in_conv: unsupported C=%d", a.C);  // (an octet count that does not divide 256 leaves the last threads idle)
   dim3 grid((a.T + STAT_TILE - 1) / STAT_TILE, B);
   if (a.Cin > 1) {
     VQVS_BY_PRECISION(precision, hipLaunchKernelGGL((in_conv_kernel<T, true>), grid, dim3(256), 0, st, a));
@@ -491,9 +528,13 @@ int launch_in_conv(const InConvArgs& a, int B, int precision, hipStream_t st) {
 
 int launch_out_conv(const OutConvArgs& a, int B, int precision, hipStream_t st) {
   const int opr = a.C / 8;
-  if (a.C % 8 || opr > 64 || (opr & (opr - 1))) VQVS_FAIL(-1, "out_conv: unsupported C=%d", a.C);
+  if (a.C % 8 || opr > 64) VQVS_FAIL(-1, "out_conv: unsupported C=%d", a.C);
   dim3 grid((a.L + STAT_TILE - 1) / STAT_TILE, B);
-  VQVS_BY_PRECISION(precision, hipLaunchKernelGGL(out_conv_kernel<T>, grid, dim3(256), 0, st, a));
+  if (opr & (opr - 1)) {
+    VQVS_BY_PRECISION(precision, hipLaunchKernelGGL(out_conv_rows_kernel<T>, grid, dim3(256), 0, st, a));
+  } else {
+    VQVS_BY_PRECISION(precision, hipLaunchKernelGGL(out_conv_kernel<T>, grid, dim3(256), 0, st, a));
+  }
   VQVS_HIP(hipGetLastError());
   return 0;
 }

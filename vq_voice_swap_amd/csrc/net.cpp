@@ -1030,8 +1030,12 @@ static int check_cfg(const vqvs_cfg& c) {
   }
   // the reference accepts any width (models/unet.py:17-30); here: powers of two from 32 to 128 (in_conv / out_conv distribute
   // C / 8 row pieces over a 256-thread workgroup; every convolution works on 32-channel K chunks)
-  if (c.base_channels != 32 && c.base_channels != 64 && c.base_channels != 128)
-    VQVS_FAIL(VQVS_ERR_ARG, "base_channels must be 32, 64 or 128 (got %d)", c.base_channels);
+  // predictor / encoder: any multiple of 32 up to 256 (unusual widths run the generic forms: 32-channel tiles, the stand-alone GroupNorm
+  // pass, the row-per-thread output convolution); the guidance models' backward kernels want a power of two
+  if (c.base_channels % 32 || c.base_channels < 32 || c.base_channels > 256)
+    VQVS_FAIL(VQVS_ERR_ARG, "base_channels must be a multiple of 32 in 32..256 (got %d)", c.base_channels);
+  if ((c.kind == VQVS_KIND_CLASSIFIER || c.kind == VQVS_KIND_ENCPRED || c.kind == VQVS_KIND_MFCC_ENCODER) && (c.base_channels & (c.base_channels - 1)))
+    VQVS_FAIL(VQVS_ERR_ARG, "base_channels must be a power of two for this kind of model (got %d)", c.base_channels);
   if (c.in_channels < 1 || c.in_channels > 64) VQVS_FAIL(VQVS_ERR_ARG, "in_channels must be in 1..64 (got %d)", c.in_channels);
   if (c.in_channels != 1 && c.kind != VQVS_KIND_PREDICTOR && c.kind != VQVS_KIND_ENCODER)
     VQVS_FAIL(VQVS_ERR_ARG, "in_channels = %d: only predictor and encoder handles take more than one input channel (the classifier stem and the "

@@ -27,6 +27,9 @@ from .unet import UNetPredictor, _NativeModule
 class EncoderPredictor(_NativeModule, Savable):
     def __init__(self, base_channels: int, downsample_rate: int, num_latents: int, bottleneck_dim: int = 64):
         super().__init__()
+        from .unet import check_base_channels
+
+        check_base_channels(base_channels, power_of_two=True)
         self.base_channels = base_channels
         self.downsample_rate = downsample_rate
         self.num_latents = num_latents

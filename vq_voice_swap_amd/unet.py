@@ -25,7 +25,19 @@ CHANNEL_MULT = (1, 1, 2, 2, 2, 4, 4, 8, 8)
 MIDDLE_DILATIONS = (4, 8, 16, 32)
 
 
-SUPPORTED_BASE_CHANNELS = (32, 64, 128)
+SUPPORTED_BASE_CHANNELS = (32, 64, 128)  # the tuned widths (the reference's two published ones and the next)
+
+
+def check_base_channels(base_channels: int, power_of_two: bool = False) -> None:
+    """The reference accepts any `base_channels` (models/unet.py:17-30).  UNetPredictor / UNetEncoder: any multiple of 32 up to 256
+    (widths other than 32 / 64 / 128 run generic forms of a few kernels: correct, not tuned); the guidance models (Classifier,
+    EncoderPredictor) and ConvMFCCEncoder: powers of two.  Fail here, with the reason, rather than at handle creation."""
+    if base_channels % 32 or not 32 <= base_channels <= 256:
+        raise ValueError(f"base_channels={base_channels}: the gfx950 library builds multiples of 32 in 32..256 "
+                         "(every convolution works on 32-channel chunks); see INTEGRATION.md")
+    if power_of_two and base_channels & (base_channels - 1):
+        raise ValueError(f"base_channels={base_channels}: this model's backward kernels need a power of two ({SUPPORTED_BASE_CHANNELS})")
+
 
 
 def check_topology(base_channels: int, channel_mult, depth_mult: int, dilations) -> None:
@@ -41,15 +53,6 @@ def check_topology(base_channels: int, channel_mult, depth_mult: int, dilations)
         raise ValueError(f"depth_mult must be an integer in 1..8 (got {depth_mult})")
     if len(dilations) > 12 or any(int(d) != d or not 1 <= d <= 32 for d in dilations):
         raise ValueError(f"dilations must be at most 12 integers in 1..32 (got {tuple(dilations)})")
-
-
-def check_base_channels(base_channels: int) -> None:
-    """The native schedule covers the reference's two published widths and 128; the reference itself accepts any
-    `base_channels` (models/unet.py:17-30).  Fail here, with the reason, rather than at handle creation."""
-    if base_channels not in SUPPORTED_BASE_CHANNELS:
-        raise ValueError(f"base_channels={base_channels}: the gfx950 library supports {SUPPORTED_BASE_CHANNELS} "
-                         "(in_conv / out_conv need a power-of-two width, every convolution 32-channel chunks); see INTEGRATION.md")
-
 
 
 def default_precision() -> str:
