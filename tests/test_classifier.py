@@ -59,6 +59,18 @@ def test_native_classifier_vs_golden(golden, precision, tol_logit, tol_grad):
     assert torch.equal(clf.log_prob_grad(x, ts, labels, 1.0), grad)
 
 
+def test_load_from_predictor_copies_the_shared_stem():
+    """classifier.py:123-131: in_conv, the time embedding and the blocks that line up with the predictor's down path."""
+    m = DiffusionModel("unet", 32)
+    det_init_(m.state_dict().items())
+    clf = Classifier(num_labels=3, base_channels=32)
+    n = clf.stem.load_from_predictor(m.predictor)
+    assert n == sum(int(v.numel()) for mod in (m.predictor.in_conv, m.predictor.time_embed, m.predictor.time_embed_extra, *m.predictor.down_blocks)
+                    for v in mod.state_dict().values())
+    assert torch.equal(clf.stem.blocks[25].post_cond[1].weight, m.predictor.down_blocks[25].post_cond[1].weight)
+    assert torch.equal(clf.stem.time_embed.proj.weight, m.predictor.time_embed.proj.weight)
+
+
 CUSTOM = [("c_a", dict(channel_mult=(1, 2, 2, 4), output_mult=8, depth_mult=1), 4096),
           ("c_b", dict(channel_mult=(1, 1, 2, 2, 2, 4), output_mult=4, depth_mult=3), 8192)]
 

@@ -58,6 +58,18 @@ class ClassifierStem(nn.Module):
                         AttentionPool1d(cur, head_channels=min(cur, 64), out_channels=self.out_channels))
 
 
+    def load_from_predictor(self, pred) -> int:
+        """Copy the stem's shared parameters from a UNetPredictor (classifier.py:123-131: in_conv, both time-embedding layers and the
+        blocks that line up with the predictor's down path); returns the number of values copied.  Host-side only."""
+        dsts = [self.in_conv, self.time_embed, self.time_embed_extra, *self.blocks]
+        srcs = [pred.in_conv, pred.time_embed, pred.time_embed_extra, *pred.down_blocks]
+        total = 0
+        for dst, src in zip(dsts, srcs):
+            dst.load_state_dict(src.state_dict())
+            total += sum(int(v.numel()) for v in src.state_dict().values())
+        return total
+
+
 class Classifier(_NativeModule, Savable):
     def __init__(self, num_labels: int, **kwargs):
         super().__init__()
