@@ -1,0 +1,85 @@
+"""Randomised topology sweep (HIP vs oracle): UNetPredictor / UNetEncoder with random base width, channel_mult, depth_mult,
+middle / output dilations, labels, conditioning of random length, input channels and batch, at short lengths.  Developer tool;
+tests/ hold the fixed cases (fixture F14 from the reference, widths 96 / 160, multi-channel input).
+    python tools/fuzz_topology.py [seed] [cases]"""
+import os
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # kernel arguments in device memory: a process-level HIP switch, before the runtime starts
+import random, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+from oracle import ref_cpu
+from vq_voice_swap_amd import UNetEncoder, UNetPredictor
+from vq_voice_swap_amd.det_init import det_init_
+from util import rel_rms, seeded
+
+dev = torch.device("cuda:0")
+rng = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+torch.set_num_threads(8)
+bad = 0
+worst = {"fp32": 0.0, "fp16": 0.0}
+for i in range(N):
+    base = rng.choice([32, 32, 64, 96, 128])
+    levels = rng.randint(1, 6)
+    mult = [1]
+    for _ in range(levels - 1):
+        mult.append(min(mult[-1] * rng.choice([1, 1, 2]), 1024 // base))
+    depth = rng.randint(1, 3)
+    dil = [rng.choice([1, 2, 3, 4, 7, 16, 32]) for _ in range(rng.randint(0, 3))]
+    rate = 2 ** (levels - 1)
+    # (bottleneck lengths from 16 rows: a GroupNorm over one to three values per group -- T = rate ... 3 * rate -- has rstd up to
+    #  1 / sqrt(eps) = 316 and amplifies ANY rounding by that much; fp16 measured 2e-2 ... 9e-2 there, fp32 1e-3: ill-conditioned
+    #  in the reference too (torch refuses the one-value case outright), not a length a 4 s clip ever has)
+    T = rate * rng.choice([16, 33, 64, 250]) if rate >= 8 else rate * rng.choice([16, 33, 64, 250, 513])
+    B = rng.choice([1, 2, 3])
+    if rng.random() < 0.65:
+        kw = {}
+        if rng.random() < 0.4:
+            kw["num_labels"] = 4
+        if rng.random() < 0.4:
+            kw["cond_channels"] = rng.choice([32, 64])
+        if rng.random() < 0.2:
+            kw["in_channels"] = rng.choice([2, 3])
+        topo = dict(channel_mult=tuple(mult), middle_dilations=tuple(dil), depth_mult=depth)
+        m = UNetPredictor(base, **topo, **kw)
+        det_init_((f"predictor.fz{i}." + k, v) for k, v in m.state_dict().items())
+        m.eval()
+        sd = {"predictor." + k: v.detach().clone() for k, v in m.state_dict().items()}
+        x, ts = seeded((B, kw.get("in_channels", 1), T), 3000 + i), torch.rand(B, generator=torch.Generator().manual_seed(i)) * 0.9 + 0.05
+        call = {}
+        if "num_labels" in kw:
+            call["labels"] = torch.randint(0, 4, (B,), generator=torch.Generator().manual_seed(100 + i))
+        if "cond_channels" in kw:
+            call["cond"] = seeded((B, kw["cond_channels"], rng.choice([1, 5, T // 64 + 1, 77])), 3500 + i, 0.5)
+        want = ref_cpu.unet_predictor(sd, base, x, ts, topology=topo, **call)
+        desc = ("predictor", base, topo, kw, T, B)
+        run = lambda: m(x.to(dev), ts.to(dev), **{k: v.to(dev) for k, v in call.items()}).cpu()
+        modes = (("fp32", 2e-4), ("fp16", 6e-3))
+    else:
+        topo = dict(channel_mult=tuple(mult), out_dilations=tuple(dil), depth_mult=depth)
+        oc = rng.choice([32, 64, 96])
+        m = UNetEncoder(base, out_channels=oc, **topo)
+        det_init_((f"encoder.fz{i}." + k, v) for k, v in m.state_dict().items())
+        m.eval()
+        sd = {"encoder." + k: v.detach().clone() for k, v in m.state_dict().items()}
+        x = seeded((B, 1, T), 3000 + i, 0.3)
+        want = ref_cpu.unet_encoder(sd, base, x, topology=topo)
+        desc = ("encoder", base, topo, oc, T, B)
+        run = lambda: m(x.to(dev)).cpu()
+        modes = (("fp32", 2e-4),)
+    for prec, tol in modes:
+        m.set_precision(prec)
+        try:
+            got = run()
+            err = rel_rms(got, want) if got.shape == want.shape else float("inf")
+        except Exception as e:  # noqa: BLE001 (a sweep reports, it does not stop)
+            err = float("inf")
+            print("EXCEPTION", prec, desc, repr(e)[:300], flush=True)
+        if err != float("inf"):
+            worst[prec] = max(worst[prec], err)
+        if not err < tol:
+            bad += 1
+            print("MISMATCH", prec, desc, err, flush=True)
+    m.invalidate()
+print("cases", N, "worst", worst, "bad", bad)
