@@ -58,7 +58,8 @@ def parse():
     ap.add_argument("--schedule", default="t**2", choices=["t", "t**2"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the measurements of the other two precision modes")
-    ap.add_argument("--other-steps", type=int, default=5, help="samples timed per other precision mode")
+    ap.add_argument("--other-steps", type=int, default=5, help="samples timed for the bf16 mode (the fp32 parity mode is timed over --steps, like the headline)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip BASELINE configs 2, 4 and 5 (one timed batch each)")
     ap.add_argument("--init-only", action="store_true", help="stop after process-group initialisation (launch-path self test)")
     ap.add_argument("--T", type=int, default=64000)
     return ap.parse_args()
@@ -93,6 +94,71 @@ def cpu_baseline(base: int, T: int, sample_steps: int):
     return {"value": clips_per_s, "unit": "clips/s", "cores": cores, "kind": "port",
             "sample": f"oracle/ref_cpu.py (torch fp32 CPU, {cores} threads of {os.cpu_count()} hw threads), unet{base}, {nb} clips x {ns} "
                       f"DDPM steps at T={T} in {dt:.1f}s, extrapolated x{sample_steps}/{ns} steps"}
+
+
+def other_configs(dev, prec: str, T: int):
+    """BASELINE.json configs 2, 4 and 5 on ONE GPU at their per-GPU share of the 8-GPU batch, in mode `prec`: one warm-up batch, one
+    timed batch each.  clips/s and the end-to-end HBM fraction = algorithmic (Model A) bytes of every forward / backward pass of the
+    batch / wall time / 8 TB/s.  Accuracy of each configuration in this mode: fixtures F6 (config 2's family), F8c (config 4), F13
+    (config 5), tests/test_scale_gpu.py."""
+    from vq_voice_swap_amd import Classifier, DiffusionModel, VQVAE, randn_clips
+    from vq_voice_swap_amd.det_init import det_init_
+
+    def det(m):
+        det_init_((k, v) for k, v in m.state_dict().items() if ".mfcc." not in k)
+        return m.eval().to(dev)
+
+    def timed(fn, warm):
+        warm()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    def entry(workload, clips, dt, by):
+        return {"workload": workload, "dtype": prec, "value": round(clips / dt, 2), "unit": "clips/s", "s_per_batch": round(dt, 3),
+                "e2e_hbm_frac": round(by / dt / (HBM_PEAK_GBPS * 1e9), 4), "algorithmic_GB_per_batch": round(by / 1e9, 1)}
+
+    out = {}
+    sq = lambda t: t ** 2  # noqa: E731
+    x = randn_clips(64, T, dev, 1)
+    m = det(DiffusionModel("unet", 32))
+    m.set_precision(prec)
+    dt = timed(lambda: m.diffusion.ddpm_sample(x, m.predictor, 50, constrain=True, schedule=sq, seed=3),
+               lambda: m.diffusion.ddpm_sample(x, m.predictor, 10, constrain=True, schedule=sq, seed=2))
+    out["config2"] = entry("unet32 50-step DDPM (constrain, schedule t**2), 64 clips of T=%d on 1 GPU" % T, 64, dt,
+                           50 * m.predictor.handle(dev, 64, T).model_bytes(64, T))
+    m.predictor.invalidate()
+    del m
+
+    v = det(VQVAE(base_channels=64, enc_name="unet", pred_name="unet", num_labels=251))
+    v.set_precision(prec)
+    wav = (0.1 * torch.randn(32, 1, T, device=dev)).clamp(-1, 1)
+    labels = torch.arange(32, device=dev) % 251
+    dt = timed(lambda: v.decode(v.encode(wav), labels, steps=50, constrain=True), lambda: v.decode(v.encode(wav), labels, steps=10, constrain=True))
+    by = 50 * v.predictor._handle.model_bytes(32, T) + v.encoder._handle.model_bytes(32, T)
+    out["config4"] = entry("VQ-VAE speaker conversion: unet64 encoder (fp32) + VQ + conditional unet64 decoder, 50 steps, 32 clips/GPU (256 over 8) "
+                           "of T=%d" % T, 32, dt, by)
+    v.predictor.invalidate()
+    v.encoder.invalidate()
+    del v
+
+    m = det(DiffusionModel("unet", 64))
+    m.set_precision(prec)
+    clf = det(Classifier(num_labels=251, base_channels=32))
+    clf.set_precision(prec)
+    x32 = x[:32].contiguous()
+    dt = timed(lambda: m.diffusion.ddpm_sample(x32, m.predictor, 100, constrain=True, cond_fn=clf.guidance_fn(labels, 1.0), seed=3),
+               lambda: m.diffusion.ddpm_sample(x32, m.predictor, 10, constrain=True, cond_fn=clf.guidance_fn(labels, 1.0), seed=2))
+    by = 100 * (m.predictor.handle(dev, 32, T).model_bytes(32, T) + clf.handle(dev, 32, T).model_bytes(32, T))
+    out["config5"] = entry("unet64 classifier-guided sampling (classifier32 forward + backward at every step), 100 steps, 32 clips/GPU (256 over 8) "
+                           "of T=%d" % T, 32, dt, by)
+    m.predictor.invalidate()
+    clf.invalidate()
+    del m, clf
+    torch.cuda.empty_cache()
+    return out
 
 
 def free_port() -> int:
@@ -356,15 +422,22 @@ def main():
             x_w = one_step(7)
             model.predictor(x_w, torch.full((end - begin,), 0.5, device=dev))
             torch.cuda.synchronize()
+            n_other = a.steps if prec == "fp32" else a.other_steps  # (the parity mode -- the number a strict reader quotes -- over the headline's sample count)
             t1 = time.perf_counter()
-            for k in range(a.other_steps):
+            for k in range(n_other):
                 model.diffusion.ddpm_sample(x_w, model.predictor, a.sample_steps, constrain=True, schedule=tmap, seed=seed + k, clip_offset=begin)
             torch.cuda.synchronize()
-            rate = round((end - begin) * a.other_steps / (time.perf_counter() - t1), 3)
+            rate = round((end - begin) * n_other / (time.perf_counter() - t1), 3)
             _h, pk, roof_o = kernel_roofline(prec)
-            others.append({"dtype": prec, "value": rate, "unit": "clips/s", "steps": a.other_steps, "note": notes[prec], "roofline": roof_o,
+            others.append({"dtype": prec, "value": rate, "unit": "clips/s", "steps": n_other, "note": notes[prec], "roofline": roof_o,
                            "forward_ms_event_sum": round(sum(d["ms"] for d in pk.values()), 3)})
         model.set_precision(a.precision)
+
+    # BASELINE.json's other configurations (2, 4, 5) at their per-GPU share, in the headline's precision mode: one timed batch each
+    # after one warm-up batch (tools/bench_configs.py is the builder-run form of the same measurement, profiles/r06_configs_1gpu.json)
+    other_cfgs = None
+    if rank == 0 and n_gpus == 1 and not a.no_other_configs and a.T == 64000:
+        other_cfgs = other_configs(dev, a.precision, a.T)
 
     if rank == 0:
         clips = n_total * a.steps
@@ -388,6 +461,7 @@ def main():
             "distributed": None if not use_dist else {"backend": backend, "world_size": world, "gather_path": gather_path()},
             "cpu_baseline": cpu,
             "other_modes": others,
+            "other_configs": other_cfgs,
             "parity": "dtype mode held to <= 1e-3 waveform RMS vs the CPU reference by tests/test_parity_gpu.py and tests/test_scale_gpu.py"
                       if a.precision in ("fp16", "fp32") else "dtype mode is OUTSIDE the 1e-3 waveform gate",
         }

@@ -80,7 +80,12 @@ typedef struct vqvs_cfg {
    * middle_dilations (4,8,16,32) / out_dilations () -- and the fields below are ignored.  topology_set = 1: they describe the
    * network: n_levels = len(channel_mult) in 1..VQVS_MAX_LEVELS, every channel_mult[i] * base_channels a multiple of 32 and at most
    * 1024; depth_mult in 1..8; n_dilations = len(middle_dilations) (predictor) or len(out_dilations) (encoder), 0 allowed, each
-   * dilation in 1..32.  T must be a multiple of 2^(n_levels - 1). */
+   * dilation in 1..32.  T must be a multiple of 2^(n_levels - 1).
+   * Limits of the builder, checked by every entry point that takes a vqvs_cfg (VQVS_ERR_ARG): predictor: channel_mult[0] == 1 (the
+   * output head normalises base_channels, unet.py:113-116 -- the reference builds such a model and fails in forward); classifier:
+   * the final width channel_mult[n_levels - 1] * base_channels at most 64 or a multiple of 64 (attention heads of 64 channels,
+   * classifier.py:131-150); every kind: the widest per-clip tensor -- max over levels of (max_T / 2^i) rows x 2 * channel_mult[i] *
+   * base_channels -- below 2 GiB at 4 bytes per element (rows of a clip are addressed by 32-bit byte offsets). */
   int32_t topology_set;
   int32_t n_levels;
   int32_t channel_mult[12];

@@ -76,9 +76,12 @@ def test_reader_decodes_downmixes_and_resamples(tmp_path):
     bad.write_bytes(b"ID3" + bytes(64))
     import shutil
 
+    trunc = tmp_path / "truncated.wav"  # a RIFF/WAVE header whose fmt chunk stops short: the same friendly error, not a struct.error
+    trunc.write_bytes(b"RIFF" + (20).to_bytes(4, "little") + b"WAVE" + b"fmt " + (8).to_bytes(4, "little") + bytes(8))
     if shutil.which("ffmpeg") is None:
-        with pytest.raises(ValueError, match="ffmpeg"):
-            ChunkReader(str(bad), 16000)
+        for f in (bad, trunc):
+            with pytest.raises(ValueError, match="ffmpeg"):
+                ChunkReader(str(f), 16000)
 
 
 def test_ulaw_codec():

@@ -70,6 +70,18 @@ def test_open_topology_param_tables(lib_built):
     cfg = UNetPredictor(32)._cfg()
     cfg.topology_set, cfg.n_levels = 1, 0
     assert lib_built.vqvs_param_count(cfg) < 0 and b"n_levels" in lib_built.vqvs_last_error()
+    # the builder's limits hold for every caller of the C ABI, not only behind the Python wrappers (include/vqvs.h, vqvs_cfg):
+    # a predictor whose first level is wider than base_channels (the output head is built for base_channels) ...
+    cfg = UNetPredictor(32)._cfg()
+    cfg.set_topology((2, 2), 2, ())
+    assert lib_built.vqvs_param_count(cfg) < 0 and b"channel_mult[0]" in lib_built.vqvs_last_error()
+    # ... and a classifier whose final width is neither <= 64 nor a multiple of 64 (attention heads of 64 channels)
+    cfg = _native.Cfg()
+    cfg.kind, cfg.base_channels, cfg.in_channels, cfg.out_channels, cfg.num_labels = _native.KIND_CLASSIFIER, 32, 1, 1, 5
+    cfg.set_topology((1, 3), 2, ())
+    assert lib_built.vqvs_param_count(cfg) < 0 and b"multiple of 64" in lib_built.vqvs_last_error()
+    cfg.set_topology((1, 4), 2, ())
+    assert lib_built.vqvs_param_count(cfg) > 0
 
 
 def test_checkpoint_roundtrip(tmp_path):

@@ -4,6 +4,8 @@ Tolerances (north_star): waveforms within 1e-3 RMS of the CPU reference; VQ code
 the waveform gate and are held to it here: "fp32" (fp32 activations, 3-term bf16-split MFMA: ~5e-6) and "fp16" (fp16
 activations and weights, f16 MFMA, fp32 statistics / accumulation: 3e-4 ... 8e-4, the benchmarked mode).  The bf16 mode
 (8 significant bits: ~1e-2 on eps, 2.6e-3 on waveforms) is outside the gate and only checked against a loose relative bound."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -217,6 +219,29 @@ def test_whole_clip_tiles_for_wide_dilations_vs_oracle(dev):
             m.set_precision(prec)
             got = m(x.to(dev), e.to(dev)).cpu()
             assert rel_rms(got, want) < tol, (prec, C, dil, L, rel_rms(got, want))
+
+
+def test_whole_clip_tiles_wide_instantiation_and_batch_invariance(dev):
+    """The whole-clip (ZP) kernel has two instantiations: 64-channel tiles where 128-channel ones would leave half of the chip idle
+    (every case above: B <= 3) and 128-channel tiles at production batch.  70 clips of 512 x 250 take the 128-channel form
+    (1 x 4 x 70 x 2 > 256 CUs): against the oracle, and BITWISE against the same clips run two at a time on the 64-channel form -- a
+    clip's bits must not depend on the batch it travels in."""
+    for i, (C, dil) in enumerate([(512, 8), (256, 32)]):
+        B, L = (70, 250) if C == 512 else (140, 250)
+        m = ResBlockModule(C, 128, None, 1.0, dil)
+        det_init_((f"zpw{i}." + k, v) for k, v in m.block.state_dict().items())
+        x, e = seeded((B, C, L), 680 + i), seeded((B, 128), 690 + i)
+        sd = {"b." + k: v.detach() for k, v in m.block.state_dict().items()}
+        pick = [0, B // 2 - 2, B - 1]
+        want = ref_cpu.res_block(x[pick], sd, "b", dict(cin=C, cout=C, scale=1.0, dil=dil), e[pick])
+        for prec, tol in (("fp16", 4e-3), ("bf16", BF16_REL)):
+            m.set_precision(prec)
+            full = m(x.to(dev), e.to(dev))
+            assert rel_rms(full[pick].cpu(), want) < tol, (prec, C, dil, rel_rms(full[pick].cpu(), want))
+            for j in pick:
+                j0 = min(j, B - 2)
+                two = m(x[j0:j0 + 2].to(dev), e[j0:j0 + 2].to(dev))
+                assert torch.equal(two[j - j0], full[j]), (prec, C, dil, j)
 
 
 def test_handle_less_entry_points_on_two_streams(dev):
@@ -633,3 +658,16 @@ def test_live_parameters_deepcopy_and_index_errors(dev):
         vq.embed(torch.tensor([[0, 512]], device=dev))
     with pytest.raises(IndexError):
         vq.embed(torch.tensor([[-1, 5]], device=dev))
+
+
+def test_random_topologies_seeded_subset(dev):
+    """A seeded 20-case subset of tools/fuzz_topology.py (random widths, channel_mult, depth_mult, dilations, labels, conditioning of
+    random length, input channels, batch; predictor in both gate modes, encoder in fp32) against the oracle: the developer sweep's
+    generator, run here as a test so that the open topology (reference unet.py:17-30, 188-196) is held by GPUTEST, not by a tool."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_topology.py"), "2026", "20"], capture_output=True, text=True, timeout=1500)
+    tail = r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.returncode == 0 and "cases 20" in r.stdout and r.stdout.rstrip().endswith("bad 0"), tail

@@ -202,12 +202,23 @@ def test_config5_unet64_with_classifier32_guidance_vs_oracle(dev):
     plain = ref_cpu.ddpm_sample("exp", x_T, lambda p, q: ref_cpu.unet_predictor(sd_m, 64, p, q), steps, noises, constrain=True)
     clf.to(dev)
     errs = []
-    for prec, bound in (("fp32", WAVE_RMS), ("fp16", None)):  # (fp16 at THREE steps: recorded, not gated -- its gate is F13, 100 steps)
+    import warnings
+
+    # fp16 at THREE guided steps: ddpm_sample promotes the call to the fp32 mode (fewer than FEW_GUIDED_STEPS guided steps in a 2-byte
+    # mode are outside the 1e-3 contract: 1.05e-3 measured, profiles/r05_parity_margins.jsonl) and says so -- the leg is gated at
+    # 1e-3 again; the modules' own modes and handles are back afterwards.  The fp16 mode's gate at config 5's step count is F13.
+    for prec, bound in (("fp32", WAVE_RMS), ("fp16", WAVE_RMS)):
         model.set_precision(prec)
         clf.set_precision(prec)
-        got = model.diffusion.ddpm_sample(x_T.to(dev), model.predictor, steps, constrain=True, cond_fn=clf.guidance_fn(labels.to(dev), scale),
-                                          noise=[n.to(dev) for n in noises]).cpu()
-        errs.append(gate(f"config 5: unet64 + classifier32 guidance, {steps} steps, T = {T}, {prec}", got, want, bound))
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            got = model.diffusion.ddpm_sample(x_T.to(dev), model.predictor, steps, constrain=True, cond_fn=clf.guidance_fn(labels.to(dev), scale),
+                                              noise=[n.to(dev) for n in noises]).cpu()
+        promoted = [w for w in rec if "run in the fp32" in str(w.message)]
+        assert bool(promoted) == (prec == "fp16"), [str(w.message) for w in rec]
+        assert model.predictor.precision == prec and clf.precision == prec
+        errs.append(gate(f"config 5: unet64 + classifier32 guidance, {steps} steps, T = {T}, {prec}"
+                         + (" (promoted to fp32 by ddpm_sample)" if prec == "fp16" else ""), got, want, bound))
     assert rms(want - plain) > 10 * errs[0], ("guidance term too small for the comparison to mean anything", errs, rms(want - plain))
     model.predictor.invalidate()
 

@@ -13,6 +13,8 @@ from __future__ import annotations
 import wave
 from typing import Optional
 
+import struct
+
 import numpy as np
 
 
@@ -104,6 +106,8 @@ def _read_wav(path: str):
         cid, size = data[pos:pos + 4], struct.unpack("<I", data[pos + 4:pos + 8])[0]
         body = data[pos + 8:pos + 8 + size]
         if cid == b"fmt ":
+            if len(body) < 16:
+                raise ValueError("truncated WAVE fmt chunk")
             tag, ch, rate, _, _, bits = struct.unpack("<HHIIHH", body[:16])
             if tag == 0xFFFE and len(body) >= 26:  # WAVE_FORMAT_EXTENSIBLE: the real tag is the sub-format GUID's first two bytes
                 tag = struct.unpack("<H", body[24:26])[0]
@@ -149,7 +153,7 @@ class ChunkReader:
             x = _resample(x, rate, sample_rate)
             # the reference sees s16le samples at this point (ffmpeg's output format): the same grid here
             self._s16 = np.clip(np.rint(x * 2 ** 15), -2 ** 15, 2 ** 15 - 1).astype("<i2")
-        except ValueError as e:
+        except (ValueError, struct.error) as e:  # (a malformed header must reach the ffmpeg fallback / the friendly error too)
             import shutil
             import subprocess
 

@@ -145,4 +145,5 @@ class Classifier(_NativeModule, Savable):
         def cond_fn(x, ts):
             return self.log_prob_grad(x, ts, labels.to(x.device), scale)
 
+        cond_fn.native_modules = (self,)  # (Diffusion.ddpm_sample promotes few-step guided runs of 2-byte models to the fp32 mode)
         return cond_fn

@@ -4,6 +4,7 @@
 #include <mutex>
 #include <string>
 #include <utility>
+#include <vector>
 
 #include "net.hpp"
 #include "sampler_kernels.hpp"
@@ -14,18 +15,35 @@ void set_error(const std::string& msg) { g_err = msg; }
 
 // scratch of the handle-less entry points (DDPM step partial sums, VQ code norms, discarded logits): one buffer per
 // (device, stream), so calls issued on different streams never share it -- work on ONE stream is ordered by the stream itself.
-// A buffer only ever grows; growing (or evicting the least recently used buffer once a device has more than MAX_STREAMS of
-// them) synchronises the OWNING device -- the current one: the map is keyed by hipGetDevice -- before the old buffer is freed,
-// so no queued kernel can still be using it.
+// A buffer only ever grows.  An entry point holds a LEASE on its buffer (ScratchLease, an in-flight count under the mutex) from
+// scratch_get until its kernels are ENQUEUED: a buffer is only freed -- by a grow on the same stream or by the eviction of the
+// least recently used buffer once a device has more than MAX_STREAMS of them -- when no lease is out on it and after the owning
+// device (the current one: the map is keyed by hipGetDevice) was synchronised, so neither a thread that has the pointer but has
+// not launched yet nor a queued kernel can still be using it.  A leased buffer that has to grow is retired instead and freed by
+// the first later call that finds the entry without leases.
 struct DeviceScratch {
   void* p = nullptr;
   size_t bytes = 0;
   unsigned long long used = 0;
+  int leases = 0;
+  std::vector<void*> retired;
 };
 static std::map<std::pair<int, void*>, DeviceScratch> g_scratch;
 static std::mutex g_scratch_mu;
 static unsigned long long g_scratch_tick = 0;
-static int scratch_get(size_t bytes, void* stream, void** out) {
+struct ScratchLease {
+  DeviceScratch* sc = nullptr;
+  void* p = nullptr;
+  ScratchLease() = default;
+  ScratchLease(const ScratchLease&) = delete;
+  ScratchLease& operator=(const ScratchLease&) = delete;
+  ~ScratchLease() {
+    if (!sc) return;
+    std::lock_guard<std::mutex> lk(g_scratch_mu);  // (std::map nodes are stable: the entry cannot have moved, and a leased one is never erased)
+    --sc->leases;
+  }
+};
+static int scratch_get(size_t bytes, void* stream, ScratchLease& lease) {
   constexpr size_t MIN_BYTES = (size_t)1 << 20;
   constexpr size_t MAX_STREAMS = 32;
   std::lock_guard<std::mutex> lk(g_scratch_mu);
@@ -38,19 +56,29 @@ static int scratch_get(size_t bytes, void* stream, void** out) {
     for (auto it = g_scratch.begin(); it != g_scratch.end(); ++it)
       if (it->first.first == dev) {
         ++n_dev;
-        if (lru == g_scratch.end() || it->second.used < lru->second.used) lru = it;
+        if (it->second.leases == 0 && (lru == g_scratch.end() || it->second.used < lru->second.used)) lru = it;
       }
-    if (n_dev >= MAX_STREAMS) {  // (streams come and go: their buffers are reclaimed here, oldest first)
-      VQVS_HIP(hipDeviceSynchronize());
-      VQVS_HIP(hipFree(lru->second.p));
+    if (n_dev >= MAX_STREAMS && lru != g_scratch.end()) {  // (streams come and go: their buffers are reclaimed here, oldest idle one first;
+      VQVS_HIP(hipDeviceSynchronize());                     //  with every buffer leased the cap is exceeded for the moment)
+      if (lru->second.p) VQVS_HIP(hipFree(lru->second.p));
+      for (void* q : lru->second.retired) VQVS_HIP(hipFree(q));
       g_scratch.erase(lru);
     }
   }
   DeviceScratch& sc = g_scratch[key];
-  if (sc.p && sc.bytes < bytes) {
+  if (sc.leases == 0 && (!sc.retired.empty() || (sc.p && sc.bytes < bytes))) {
     VQVS_HIP(hipDeviceSynchronize());
-    VQVS_HIP(hipFree(sc.p));
-    sc = DeviceScratch{};
+    for (void* q : sc.retired) VQVS_HIP(hipFree(q));
+    sc.retired.clear();
+    if (sc.p && sc.bytes < bytes) {
+      VQVS_HIP(hipFree(sc.p));
+      sc.p = nullptr;
+      sc.bytes = 0;
+    }
+  } else if (sc.p && sc.bytes < bytes) {  // (another thread on the same stream still holds the smaller buffer: retire it, free it later)
+    sc.retired.push_back(sc.p);
+    sc.p = nullptr;
+    sc.bytes = 0;
   }
   if (!sc.p) {
     size_t n = bytes < MIN_BYTES ? MIN_BYTES : bytes;
@@ -58,7 +86,9 @@ static int scratch_get(size_t bytes, void* stream, void** out) {
     sc.bytes = n;
   }
   sc.used = ++g_scratch_tick;
-  *out = sc.p;
+  ++sc.leases;
+  lease.sc = &sc;
+  lease.p = sc.p;
   return 0;
 }
 }  // namespace vqvs
@@ -231,10 +261,10 @@ int vqvs_classifier_guidance(vqvs_model* m, const float* d_x, const float* d_ts,
   if (int e = check_run(m, VQVS_KIND_CLASSIFIER, B, T)) return e;
   if (!d_x || !d_ts || !d_labels || !d_grad) VQVS_FAIL(VQVS_ERR_ARG, "x, ts, labels and grad must be non-NULL");
   float* logits = d_logits;
+  ScratchLease lease;  // (held until run_model has enqueued every kernel)
   if (!logits) {
-    void* scratch = nullptr;
-    if (int e = scratch_get((size_t)B * m->cfg.num_labels * 4, stream, &scratch)) return e;
-    logits = reinterpret_cast<float*>(scratch);
+    if (int e = scratch_get((size_t)B * m->cfg.num_labels * 4, stream, lease)) return e;
+    logits = reinterpret_cast<float*>(lease.p);
   }
   RunCtx c;
   c.B = B;
@@ -288,10 +318,10 @@ int vqvs_ddpm_step(const float* d_x_t, const float* d_eps, const float* d_noise,
                    uint32_t step_index, void* stream) {
   if (!d_x_t || !d_eps || !d_alpha_t || !d_alpha_prev || !d_x_prev) VQVS_FAIL(VQVS_ERR_ARG, "NULL argument");
   if (B < 1 || T < 1) VQVS_FAIL(VQVS_ERR_ARG, "bad shape B=%d T=%d", B, T);
-  void* scratch = nullptr;
+  ScratchLease lease;
   if (flags & VQVS_DDPM_CONSTRAIN)
-    if (int e = scratch_get((size_t)ddpm_scratch_doubles(B, T) * 8, stream, &scratch)) return e;
-  return run_ddpm_step(d_x_t, d_eps, d_noise, d_alpha_t, d_alpha_prev, d_x_prev, reinterpret_cast<double*>(scratch), B, T, flags,
+    if (int e = scratch_get((size_t)ddpm_scratch_doubles(B, T) * 8, stream, lease)) return e;
+  return run_ddpm_step(d_x_t, d_eps, d_noise, d_alpha_t, d_alpha_prev, d_x_prev, reinterpret_cast<double*>(lease.p), B, T, flags,
                        noise_scale, seed, clip_offset, step_index, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -316,9 +346,9 @@ int vqvs_vq_argmin(const float* d_z, const float* d_dict, int64_t* d_idx, int B,
   if (!d_z || !d_dict || !d_idx) VQVS_FAIL(VQVS_ERR_ARG, "NULL argument");
   if (B < 1 || Cd < 1 || T1 < 1 || K < 1) VQVS_FAIL(VQVS_ERR_ARG, "bad shape");
   if (Cd % 4) VQVS_FAIL(VQVS_ERR_ARG, "Cd must be a multiple of 4 (got %d)", Cd);
-  void* scratch = nullptr;
-  if (int e = scratch_get((size_t)K * 4, stream, &scratch)) return e;
-  return run_vq_argmin(d_z, d_dict, reinterpret_cast<float*>(scratch), d_idx, B, Cd, T1, K, reinterpret_cast<hipStream_t>(stream));
+  ScratchLease lease;
+  if (int e = scratch_get((size_t)K * 4, stream, lease)) return e;
+  return run_vq_argmin(d_z, d_dict, reinterpret_cast<float*>(lease.p), d_idx, B, Cd, T1, K, reinterpret_cast<hipStream_t>(stream));
 }
 
 int vqvs_vq_embed(const int64_t* d_idx, const float* d_dict, float* d_out, int B, int Cd, int T1, int K, void* stream) {

@@ -926,8 +926,31 @@ static int check_topology(const vqvs_cfg& c) {
     if (c.n_dilations < 0 || c.n_dilations > 12) VQVS_FAIL(VQVS_ERR_ARG, "at most 12 middle / output dilations (got %d)", c.n_dilations);
     for (int i = 0; i < c.n_dilations; ++i)
       if (c.dilations[i] < 1 || c.dilations[i] > 32) VQVS_FAIL(VQVS_ERR_ARG, "dilation %d is outside 1..32", c.dilations[i]);
+    // Limits of the BUILDER, enforced here for every caller of the C ABI (the Python wrappers raise the same errors earlier):
+    // * predictor: the output head (out.0.0 GroupNorm + out.1 conv, unet.py:113-116) is built for base_channels, the last up block
+    //   returns channel_mult[0] * base_channels -- the reference constructs such a model and fails in forward;
+    // * classifier: the attention pool splits the final width into heads of 64 channels (classifier.py:131-150 asserts the same).
+    if (c.kind == VQVS_KIND_PREDICTOR && c.channel_mult[0] != 1)
+      VQVS_FAIL(VQVS_ERR_ARG, "predictor channel_mult[0] must be 1 (got %d): the output head is built for base_channels", c.channel_mult[0]);
+    if (c.kind == VQVS_KIND_CLASSIFIER) {
+      const int cur = c.channel_mult[c.n_levels - 1] * c.base_channels;
+      if (cur > 64 && cur % 64)
+        VQVS_FAIL(VQVS_ERR_ARG, "classifier: the final width %d must be at most 64 or a multiple of 64 (attention heads of 64 channels)", cur);
+    }
   }
   return 0;
+}
+
+// elements of the widest per-clip tensor a launch may address: level i holds max_T / 2^i rows of channel_mult[i] * base channels, and a
+// concatenated input (the predictor's up path) is twice that wide.  (The default topology: max_T rows of 2 * base channels.)
+static long long widest_clip_elems(const vqvs_cfg& c) {
+  const Topo t = topo_of(c);
+  long long best = 0;
+  for (int i = 0; i < t.levels(); ++i) {
+    const long long rows = ((long long)c.max_T >> i) + 1;
+    best = std::max(best, rows * t.mult[i] * c.base_channels * 2);
+  }
+  return best;
 }
 
 int enumerate_params(const vqvs_cfg& c, std::vector<ParamDef>& out) {
@@ -1053,8 +1076,9 @@ static int check_cfg(const vqvs_cfg& c) {
     if (c.max_T % rate) VQVS_FAIL(VQVS_ERR_ARG, "max_T must be a multiple of the downsample rate %d (got %d)", rate, c.max_T);
   }
   // the kernels address rows of one clip with 32-bit byte offsets (buffer loads): the widest per-clip tensor must stay below 2 GiB
-  if ((long long)c.max_T * c.base_channels * 8 > 0x7fffffffLL)
-    VQVS_FAIL(VQVS_ERR_ARG, "max_T=%d is too long for base_channels=%d (a clip's top-level tensor would exceed 2 GiB)", c.max_T, c.base_channels);
+  // (4 bytes per element in the fp32 mode; the widest tensor a launch addresses is a level's concatenated input, 2 x its width)
+  if (widest_clip_elems(c) * 4 > 0x7fffffffLL)
+    VQVS_FAIL(VQVS_ERR_ARG, "max_T=%d is too long for base_channels=%d with this topology (a clip's widest tensor would exceed 2 GiB)", c.max_T, c.base_channels);
   if (c.kind == VQVS_KIND_PREDICTOR) {
     if (c.out_channels != 1 && (c.out_channels % 32)) VQVS_FAIL(VQVS_ERR_ARG, "out_channels must be 1 or a multiple of 32");
     if (c.cond_channels % 32) VQVS_FAIL(VQVS_ERR_ARG, "cond_channels must be a multiple of 32");

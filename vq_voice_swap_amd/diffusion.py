@@ -60,6 +60,28 @@ def _rows(v: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
 
 NoiseSource = Union[None, Sequence[torch.Tensor], Callable[[int], torch.Tensor]]
 
+FEW_GUIDED_STEPS = 10  # a guided run of fewer steps is promoted to the fp32 mode (ddpm_sample)
+
+
+def _native_modules(fn) -> list:
+    """The native (precision-mode) modules behind a predictor / cond_fn callable: the module itself, the target of a
+    functools.partial (`UNetPredictor.condition`), the owner of a bound method, or what a closure advertises as `native_modules`
+    (`Classifier.guidance_fn`).  Anything else -- a plain Python function -- has none: nothing is promoted."""
+    seen, out = set(), []
+
+    def add(m):
+        if m is not None and hasattr(m, "precision_override") and id(m) not in seen:
+            seen.add(id(m))
+            out.append(m)
+
+    add(fn)
+    add(getattr(fn, "func", None))
+    add(getattr(fn, "__self__", None))
+    add(getattr(getattr(fn, "func", None), "__self__", None))
+    for m in getattr(fn, "native_modules", ()) or ():
+        add(m)
+    return out
+
 
 class Diffusion:
     def __init__(self, schedule: Schedule):
@@ -165,6 +187,32 @@ class Diffusion:
         _native.require_cuda(x_T)
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        # Few guided steps in a 2-byte mode: the first reverse step multiplies the predictor's rounding error by 1 / sqrt(alpha_bar(1))
+        # and a guided run adds the classifier gradient's own; fewer than FEW_GUIDED_STEPS iterations never average that out (measured:
+        # config 5 at 3 steps 1.05e-3 in fp16 against the 1e-3 waveform contract, profiles/r05_parity_margins.jsonl).  The call is then
+        # promoted to the fp32 mode -- predictor and guidance model -- through precision_override, which keeps each module's own
+        # handle; VQVAE.decode_uncond_guidance does the same for its extrapolation.  (VQVS_FEW_STEP_PROMOTE=0: warn only.)
+        promote = []
+        if cond_fn is not None and steps < FEW_GUIDED_STEPS:
+            promote = [m for m in _native_modules(predictor) + _native_modules(cond_fn) if getattr(m, "precision", "fp32") != "fp32"]
+        if promote:
+            import contextlib
+            import os
+            import warnings
+
+            modes = sorted({m.precision for m in promote})
+            if os.environ.get("VQVS_FEW_STEP_PROMOTE", "1") == "0":
+                warnings.warn(f"ddpm_sample: {steps} guided steps in the {modes} mode(s) are outside the 1e-3 waveform contract "
+                              f"(fewer than {FEW_GUIDED_STEPS} steps); VQVS_FEW_STEP_PROMOTE=0 keeps the mode", RuntimeWarning, stacklevel=2)
+            else:
+                warnings.warn(f"ddpm_sample: {steps} guided steps (fewer than {FEW_GUIDED_STEPS}): predictor / guidance model run in the fp32 "
+                              f"mode for this call (their {modes} mode(s) do not hold the 1e-3 waveform contract at so few steps)",
+                              RuntimeWarning, stacklevel=2)
+                with contextlib.ExitStack() as stack:
+                    for m in promote:
+                        stack.enter_context(m.precision_override("fp32"))
+                    return self.ddpm_sample(x_T, predictor, steps, progress=progress, sigma_large=sigma_large, constrain=constrain,
+                                            cond_fn=cond_fn, schedule=schedule, noise=noise, seed=seed, clip_offset=clip_offset)
         x_t = x_T
         B = x_T.shape[0]
         t_values = [(i + 1) / steps for i in range(steps)][::-1]

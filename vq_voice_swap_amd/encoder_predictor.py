@@ -101,4 +101,5 @@ class EncoderPredictor(_NativeModule, Savable):
         def cond_fn(x, ts):
             return self.guidance_grad(x, ts, targets.to(x.device), scale)
 
+        cond_fn.native_modules = (self,)  # (see Classifier.guidance_fn)
         return cond_fn

@@ -224,7 +224,9 @@ class _NativeModule(nn.Module):
 
     def handle(self, device: torch.device, B: int, T: int) -> _native.Handle:
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        key = (idx, self.precision, bool(self.debug_taps), self._weights_token())
+        # (everything the native handle is BUILT from besides the shapes: the conditioning-length code is part of the key, so a handle
+        #  restored by precision_override after the code changed inside the override is rebuilt instead of reused)
+        key = (idx, self.precision, bool(self.debug_taps), self._weights_token(), getattr(self, "_cond_code", 0))
         h = self._handle
         if h is not None and self._handle_key == key and h.cfg.max_batch >= B and h.cfg.max_T >= T:
             return h
