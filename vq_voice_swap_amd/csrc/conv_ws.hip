@@ -635,6 +635,28 @@ __global__ __launch_bounds__((ws_threads<T, ROWS>())) void conv_ws_kernel(const 
     sync_lds();
     int q = 0;
     WS_TMARK(2)
+#ifndef VQVS_WS_PREP_EARLY
+#define VQVS_WS_PREP_EARLY 1  // (0: the cursor runs behind the barrier, as through round 5 -- A/B)
+#endif
+#if VQVS_WS_PREP_EARLY
+    // the parameters of the loads a step issues are computed at the END of the step before it, in front of the barrier -- scalar work
+    // that would otherwise run right behind the barrier, beside the consumers' MFMA burst, now fills the wait for the other waves
+    Prep prn = prepare();
+#define WS_PBODY(R)              \
+  {                              \
+    WS_TMARK(2)                  \
+    acquire(R);                  \
+    WS_TMARK(0)                  \
+    stage(R, q & 1);             \
+    WS_TMARK(1)                  \
+    issue(R, prn);               \
+    prn = prepare();             \
+    WS_TMARK(4)                  \
+    sync_lds();                  \
+    WS_TMARK(3)                  \
+  }                              \
+  if (++q == Q) break;
+#else
 #define WS_PBODY(R)              \
   {                              \
     const Prep pr = prepare();   \
@@ -649,6 +671,7 @@ __global__ __launch_bounds__((ws_threads<T, ROWS>())) void conv_ws_kernel(const 
     WS_TMARK(3)                  \
   }                              \
   if (++q == Q) break;
+#endif
     for (;;) {
       WS_PBODY(R0)
       WS_PBODY(R1)
