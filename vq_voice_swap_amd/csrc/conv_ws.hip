@@ -185,7 +185,8 @@ struct TileCo {
 #ifndef VQVS_WS_EXP
 #define VQVS_WS_EXP 0  // ablation bits for tools/experiments (results are WRONG when non-zero): 1 no activation loads, 2 no weight DMA,
 #endif                // 4 no tile store, 8 no prologue arithmetic, 16 no MFMA loop, 32 no tile-end statistics / rounding, 64 constant
-                      // (scale, shift), 128 no zero masks, 256 store at the step's start, 1024 idle consumers, 2048 trivial load cursor, 4096 fragment reads without MFMAs, 32768 no barriers inside the step loop
+                      // (scale, shift), 128 no zero masks, 256 store at the step's start, 1024 idle consumers, 2048 trivial load cursor, 4096 fragment reads without MFMAs, 32768 no barriers inside the step loop,
+                      // 131072 every second step barrier skipped (what would two K chunks per barrier be worth?)
 
 #ifdef VQVS_TIMING
 __device__ unsigned long long g_ws_timing[32];
@@ -319,9 +320,10 @@ __global__ __launch_bounds__((ws_threads<T, ROWS>())) void conv_ws_kernel(const 
       }
     }
   };
+  bool skipb = false;  // (ablation bit 131072: the next step barrier is left out)
   auto sync_lds = [&]() {  // LDS writes / reads of this wave are done; global loads stay in flight across the barrier
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (!(VQVS_WS_EXP & 32768)) __builtin_amdgcn_s_barrier();
+    if (!(VQVS_WS_EXP & 32768) && !((VQVS_WS_EXP & 131072) && skipb)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
 
@@ -652,7 +654,9 @@ __global__ __launch_bounds__((ws_threads<T, ROWS>())) void conv_ws_kernel(const 
     issue(R, prn);               \
     prn = prepare();             \
     WS_TMARK(4)                  \
+    skipb = (q & 1) != 0;        \
     sync_lds();                  \
+    skipb = false;               \
     WS_TMARK(3)                  \
   }                              \
   if (++q == Q) break;
@@ -803,7 +807,7 @@ __global__ __launch_bounds__((ws_threads<T, ROWS>())) void conv_ws_kernel(const 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       else
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      if (!(VQVS_WS_EXP & 32768)) __builtin_amdgcn_s_barrier();
+      if (!(VQVS_WS_EXP & 32768) && !((VQVS_WS_EXP & 131072) && skipb)) __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     };
 
@@ -1284,10 +1288,12 @@ __global__ __launch_bounds__((ws_threads<T, ROWS>())) void conv_ws_kernel(const 
         if (!(VQVS_WS_EXP & 4) && i0 < NIT) store_tile(i0, i1 < NIT ? i1 : NIT);
         if (i1 >= NIT) pending = false;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (!(VQVS_WS_EXP & 32768)) __builtin_amdgcn_s_barrier();
+        if (!(VQVS_WS_EXP & 32768) && !((VQVS_WS_EXP & 131072) && (g & 1) == 0 && g < Q - 1)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
       } else {
+        skipb = (g & 1) == 0 && g < Q - 1;
         sync_all();
+        skipb = false;
       }
       WS_TMARK(4)
     }
