@@ -157,6 +157,14 @@ def test_fp16_range_guard_trips():
     model.set_precision("fp32")
     out = model.diffusion.ddpm_sample(x_T.to(dev), model.predictor, 3, constrain=True, noise=noises)
     assert bool(torch.isfinite(out).all())
+    # a non-finite value that never passes a GroupNorm in a 2-byte tensor -- here an inf in the LAST step's noise -- is caught on the
+    # finished sample (x_t is fp32 in every mode: the library's guard does not see it)
+    det_init_(model.state_dict().items())
+    model.set_precision("fp16")
+    bad = [n.clone() for n in noises]
+    bad[1][0, 0, 7] = float("inf")
+    with pytest.raises(_native.NativeError, match="non-finite"):
+        model.diffusion.ddpm_sample(x_T.to(dev), model.predictor, 3, noise=bad)
 
 
 def test_config4_base64_decode_vs_oracle(dev):

@@ -250,8 +250,17 @@ class Diffusion:
                                  constrain=constrain, cond_fn=cond_fn, seed=seed, clip_offset=clip_offset, step_index=i,
                                  noise_scale=0.0 if last else 1.0)
         chk = getattr(predictor, "check_status", None)  # range guard of a native predictor: once per sample, not per step
+        if chk is None:
+            mods = _native_modules(predictor)
+            chk = mods[0].check_status if mods else None
         if chk is not None:
             chk()
+            # The library's guard sees the tensors that feed a GroupNorm.  The network's output and x_t are fp32 in every mode and cannot
+            # overflow a storage type, but a non-finite value can still reach them (an inf / NaN in x_T, in the conditioning or in a
+            # cond_fn's gradient): the finished sample is checked here, on the sync check_status() has just paid for.
+            if not bool(torch.isfinite(x_t).all()):
+                raise _native.NativeError("ddpm_sample: the sample holds non-finite values (a non-finite x_T, conditioning tensor or "
+                                          "guidance gradient, or an overflow the range guard reported as a warning)")
         return x_t
 
 
