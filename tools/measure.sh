@@ -12,7 +12,7 @@ export TMPDIR=/tmp
 timeout 900 python bench.py --precision $PREC > $OUT/bench_$PREC.json 2> $OUT/bench_$PREC.err; tail -c 400 $OUT/bench_$PREC.json
 timeout 300 python tools/profile_ops.py --precision $PREC > $OUT/ops_unet64_$PREC.txt 2>&1
 cd /tmp && rm -rf /tmp/prof_stats
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o stats -- python $GRAFT_REPO_ROOT/bench.py --precision $PREC --steps 2 --warmup 0 --no-cpu-baseline --no-other-modes > $OUT/bench_under_rocprof_$PREC.json 2> $OUT/bench_under_rocprof_$PREC.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o stats -- python $GRAFT_REPO_ROOT/bench.py --precision $PREC --steps 2 --warmup 0 --no-cpu-baseline --no-other-modes --no-other-configs > $OUT/bench_under_rocprof_$PREC.json 2> $OUT/bench_under_rocprof_$PREC.err
 cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_$PREC.csv
 head -5 $OUT/kernel_stats_$PREC.csv
 if [ "$3" != "nopmc" ]; then
