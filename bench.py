@@ -27,6 +27,9 @@ Rank 0 prints ONE JSON line.  Extra objects:
                  only when that summary is stamped with the build id of the library loaded here.
   cpu_baseline - the CPU oracle (oracle/ref_cpu.py, stock torch fp32 on the host cores) on a bounded
                  sample of the same workload, extrapolated to 50 steps.  Reported baseline, not the target.
+  other_modes  - the same workload in the other two precision modes (fp32 parity mode over --steps samples, bf16 over --other-steps).
+  other_configs- BASELINE.json configs 2, 4 and 5 at their per-GPU share (rank 0, one GPU): one timed batch each after one warm-up
+                 batch, clips/s and end-to-end HBM fraction.  Not part of `value`; --no-other-configs skips them.
 """
 import argparse
 
