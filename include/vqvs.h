@@ -63,7 +63,7 @@ typedef struct vqvs_model vqvs_model;
 
 typedef struct vqvs_cfg {
   int32_t kind;          /* VQVS_KIND_* */
-  int32_t base_channels; /* multiple of 32 in 32..256 (reference configs: 32, 64; tuned: 32, 64, 128); classifier / encoder predictor / MFCC encoder: a power of two */
+  int32_t base_channels; /* multiple of 32 in 32..256 (reference configs: 32, 64; tuned: 32, 64, 128); MFCC encoder: a power of two */
   int32_t in_channels;   /* 1 (the reference's default and every caller's value, unet.py:25) .. 64; predictor / encoder handles only */
   int32_t out_channels;  /* predictor: 1 or a multiple of 32; encoder: multiple of 32 */
   int32_t cond_channels; /* 0 = unconditional (unet.py:46-47) */

@@ -234,3 +234,27 @@ def test_guidance_gradient_is_batch_independent_at_full_size():
     for i in (0, 17, 31):
         g1, l1 = clf.log_prob_grad(x[i:i + 1], ts[i:i + 1], labels[i:i + 1], scale=1.0, return_logits=True)
         assert torch.equal(g1[0], g_all[i]) and torch.equal(l1[0], logits_all[i]), i
+
+
+@pytest.mark.gpu
+def test_classifier_width_96_vs_oracle():
+    """The reference takes any base width (classifier.py:52-58); the library builds every multiple of 32 (round 6: the guidance
+    models no longer need a power of two -- in_conv_bw / bw_act have forms for rows whose octet count is not one).  base 96 with a
+    short topology (final width 384 = 6 heads of 64) and base 160 (final width 320 = 5 heads): logits and d log p / dx."""
+    dev = torch.device("cuda:0")
+    for base, kw, T in ((96, dict(channel_mult=(1, 2, 4), output_mult=2, depth_mult=1), 2048),
+                        (160, dict(channel_mult=(1, 2), output_mult=2, depth_mult=2), 1024)):
+        clf = Classifier(num_labels=5, base_channels=base, **kw)
+        det_init_((f"clf.w{base}." + k, v) for k, v in clf.state_dict().items())
+        clf.eval()
+        sd = {k: v.detach().clone() for k, v in clf.state_dict().items()}
+        x, ts, labels = seeded((2, 1, T), 300 + base), torch.tensor([0.2, 0.7]), torch.tensor([1, 4])
+        topo = dict(channel_mult=kw["channel_mult"], depth_mult=kw["depth_mult"])
+        want = ref_cpu.classifier(sd, base, x, ts, topology=topo)
+        want_g = ref_cpu.classifier_cond_fn(sd, base, labels, 1.0, topology=topo)(x, ts)
+        clf.to(dev)
+        for prec, tl, tg in (("fp32", 2e-4, 2e-3), ("fp16", 8e-3, 3e-2)):
+            clf.set_precision(prec)
+            g, lg = clf.log_prob_grad(x.to(dev), ts.to(dev), labels.to(dev), 1.0, return_logits=True)
+            assert rel_rms(lg.cpu(), want) < tl, (base, prec, rel_rms(lg.cpu(), want))
+            assert rel_rms(g.cpu(), want_g) < tg, (base, prec, rel_rms(g.cpu(), want_g))

@@ -131,3 +131,25 @@ def test_base64_guidance_models_vs_oracle():
     ep.to(dev)
     assert rel_rms(ep(x.to(dev), ts.to(dev)).cpu(), want) < 2e-4
     assert rel_rms(ep.guidance_grad(x.to(dev), ts.to(dev), tg.to(dev)).cpu(), want_g) < 2e-3
+
+
+@pytest.mark.gpu
+def test_encpred_width_96_vs_oracle():
+    """EncoderPredictor at a base width that is not a power of two (the reference takes any, encoder_predictor.py:25-41): logits and
+    the input gradient of the summed cross-entropy through the whole UNet against the oracle."""
+    dev = torch.device("cuda:0")
+    ep = EncoderPredictor(base_channels=96, downsample_rate=256, num_latents=40, bottleneck_dim=64)
+    det_init_(("ep96." + k, v) for k, v in ep.state_dict().items())
+    ep.eval()
+    sd = {k: v.detach().clone() for k, v in ep.state_dict().items()}
+    T = 16384
+    x, ts = seeded((2, 1, T), 961), torch.tensor([0.3, 0.8])
+    targets = torch.randint(0, 40, (2, T // 256), generator=torch.Generator().manual_seed(962))
+    want = ref_cpu.encoder_predictor(sd, 96, x, ts, 256)
+    want_g = ref_cpu.encoder_predictor_cond_fn(sd, 96, 256, targets, 1.0)(x, ts)
+    ep.to(dev)
+    for prec, tl, tg in (("fp32", 2e-4, 2e-3), ("fp16", 8e-3, 4e-2)):
+        ep.set_precision(prec)
+        assert rel_rms(ep(x.to(dev), ts.to(dev)).cpu(), want) < tl, prec
+        g = ep.guidance_grad(x.to(dev), ts.to(dev), targets.to(dev), 1.0).cpu()
+        assert rel_rms(g, want_g) < tg, (prec, rel_rms(g, want_g))

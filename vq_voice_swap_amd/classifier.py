@@ -75,7 +75,7 @@ class Classifier(_NativeModule, Savable):
         super().__init__()
         self.num_labels = num_labels
         self.stem = ClassifierStem(**kwargs)
-        check_base_channels(self.stem.base_channels, power_of_two=True)
+        check_base_channels(self.stem.base_channels)
         check_topology(self.stem.base_channels, self.stem.channel_mult, self.stem.depth_mult, ())  # (classifier.py:52-58: any of these)
         if int(self.stem.output_mult) != self.stem.output_mult or not 1 <= self.stem.output_mult * self.stem.base_channels <= 4096:
             raise ValueError(f"output_mult={self.stem.output_mult}: the feature width must be in 1..4096")

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void bw_act_kernel(const BwActArgs a) {
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gn_bw_kernel(const GnBwArgs a) {
   __shared__ double part[256 * 2];
-  __shared__ double chs[1024], chq[1024];
+  __shared__ double chs[2048], chq[2048];  // (up to 2 x 1024 channels: the concatenated input of the widest up block)
   __shared__ double gA[32], gB[32];
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
@@ -311,6 +311,39 @@ __global__ __launch_bounds__(256) void in_conv_bw_kernel(const InConvBwArgs a) {
   }
   __syncthreads();
   // forward: h[t][c] += w[c][k] * x[t+k-1]  =>  dx[t] = sum_k p_k[t-k+1];  y[.][r] holds row t0-1+r
+  const int t = t0 + tid;
+  if (t < a.T) a.out[(size_t)b * a.T + t] = (y[0][tid + 2] + y[1][tid + 1] + y[2][tid]) * a.out_scale;
+}
+
+// in_conv_bw for widths whose octet count is not a power of two (base_channels 96, 160, ...: the shuffle reduction above needs a
+// row's lanes to be a power-of-two group inside one wave): one thread = one row, all channels, the channel sum in channel order --
+// the counterpart of out_conv_rows_kernel (misc_kernels.hip).  A fallback for unusual widths, not a tuned kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void in_conv_bw_rows_kernel(const InConvBwArgs a) {
+  __shared__ float y[3][STAT_TILE + 2];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * STAT_TILE;
+  for (int r = tid; r < STAT_TILE + 2; r += 256) {
+    const int t = t0 - 1 + r;
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+    if (t >= 0 && t < a.T) {
+      const T* row = reinterpret_cast<const T*>(a.dh) + ((size_t)b * a.T + t) * a.C;
+      for (int c = 0; c < a.C; c += 8) {
+        const f32x8 v = Elem<T>::load8(row + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          p0 = fmaf(a.w[(c + j) * 3 + 0], v[j], p0);
+          p1 = fmaf(a.w[(c + j) * 3 + 1], v[j], p1);
+          p2 = fmaf(a.w[(c + j) * 3 + 2], v[j], p2);
+        }
+      }
+    }
+    y[0][r] = p0;
+    y[1][r] = p1;
+    y[2][r] = p2;
+  }
+  __syncthreads();
   const int t = t0 + tid;
   if (t < a.T) a.out[(size_t)b * a.T + t] = (y[0][tid + 2] + y[1][tid + 1] + y[2][tid]) * a.out_scale;
 }
@@ -605,7 +638,7 @@ size_t head_lds_floats(const HeadArgs& a) {
 
 int launch_bw_act(const BwActArgs& a, int B, int precision, hipStream_t st) {
   const int opr = a.C / 8;
-  if (a.C % 8 || opr > 256 || 256 % opr) VQVS_FAIL(-1, "bw_act: unsupported C=%d", a.C);
+  if (a.C % 8 || opr > 256) VQVS_FAIL(-1, "bw_act: unsupported C=%d", a.C);  // (256 % opr != 0: the last 256 - rpp * opr threads idle)
   if (a.resize == BW_FROM_HALF && (a.L & 1)) VQVS_FAIL(-1, "bw_act: avg-pool backward needs an even length");
   dim3 grid((a.L + STAT_TILE - 1) / STAT_TILE, B);
   VQVS_BY_PRECISION(precision, hipLaunchKernelGGL(bw_act_kernel<T>, grid, dim3(256), 0, st, a));
@@ -614,7 +647,7 @@ int launch_bw_act(const BwActArgs& a, int B, int precision, hipStream_t st) {
 }
 
 int launch_gn_bw(const GnBwArgs& a, int B, hipStream_t st) {
-  if (a.C > 1024 || a.groups > 32 || a.C % a.groups) VQVS_FAIL(-1, "gn_bw: unsupported C=%d groups=%d", a.C, a.groups);
+  if (a.C > 2048 || a.groups > 32 || a.C % a.groups) VQVS_FAIL(-1, "gn_bw: unsupported C=%d groups=%d", a.C, a.groups);
   hipLaunchKernelGGL(gn_bw_kernel, dim3(B), dim3(256), 0, st, a);
   VQVS_HIP(hipGetLastError());
   return 0;
@@ -631,9 +664,13 @@ int launch_bw_affine(const BwAffineArgs& a, int B, int precision, hipStream_t st
 
 int launch_in_conv_bw(const InConvBwArgs& a, int B, int precision, hipStream_t st) {
   const int opr = a.C / 8;
-  if (a.C % 8 || opr > 64 || (opr & (opr - 1))) VQVS_FAIL(-1, "in_conv_bw: unsupported C=%d", a.C);
+  if (a.C % 8 || opr > 64) VQVS_FAIL(-1, "in_conv_bw: unsupported C=%d", a.C);
   dim3 grid((a.T + STAT_TILE - 1) / STAT_TILE, B);
-  VQVS_BY_PRECISION(precision, hipLaunchKernelGGL(in_conv_bw_kernel<T>, grid, dim3(256), 0, st, a));
+  if (opr & (opr - 1)) {
+    VQVS_BY_PRECISION(precision, hipLaunchKernelGGL(in_conv_bw_rows_kernel<T>, grid, dim3(256), 0, st, a));
+  } else {
+    VQVS_BY_PRECISION(precision, hipLaunchKernelGGL(in_conv_bw_kernel<T>, grid, dim3(256), 0, st, a));
+  }
   VQVS_HIP(hipGetLastError());
   return 0;
 }

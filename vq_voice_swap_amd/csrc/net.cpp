@@ -1057,7 +1057,9 @@ static int check_cfg(const vqvs_cfg& c) {
   // pass, the row-per-thread output convolution); the guidance models' backward kernels want a power of two
   if (c.base_channels % 32 || c.base_channels < 32 || c.base_channels > 256)
     VQVS_FAIL(VQVS_ERR_ARG, "base_channels must be a multiple of 32 in 32..256 (got %d)", c.base_channels);
-  if ((c.kind == VQVS_KIND_CLASSIFIER || c.kind == VQVS_KIND_ENCPRED || c.kind == VQVS_KIND_MFCC_ENCODER) && (c.base_channels & (c.base_channels - 1)))
+  // (round 6: the guidance models take any multiple of 32 too -- in_conv_bw and bw_act have row-per-thread / partial-pass forms for widths
+  //  whose octet count is not a power of two; the MFCC encoder's 12 * base wide stack stays on powers of two)
+  if (c.kind == VQVS_KIND_MFCC_ENCODER && (c.base_channels & (c.base_channels - 1)))
     VQVS_FAIL(VQVS_ERR_ARG, "base_channels must be a power of two for this kind of model (got %d)", c.base_channels);
   if (c.in_channels < 1 || c.in_channels > 64) VQVS_FAIL(VQVS_ERR_ARG, "in_channels must be in 1..64 (got %d)", c.in_channels);
   if (c.in_channels != 1 && c.kind != VQVS_KIND_PREDICTOR && c.kind != VQVS_KIND_ENCODER)

@@ -29,7 +29,7 @@ class EncoderPredictor(_NativeModule, Savable):
         super().__init__()
         from .unet import check_base_channels
 
-        check_base_channels(base_channels, power_of_two=True)
+        check_base_channels(base_channels)
         self.base_channels = base_channels
         self.downsample_rate = downsample_rate
         self.num_latents = num_latents

@@ -30,13 +30,14 @@ SUPPORTED_BASE_CHANNELS = (32, 64, 128)  # the tuned widths (the reference's two
 
 def check_base_channels(base_channels: int, power_of_two: bool = False) -> None:
     """The reference accepts any `base_channels` (models/unet.py:17-30).  UNetPredictor / UNetEncoder: any multiple of 32 up to 256
-    (widths other than 32 / 64 / 128 run generic forms of a few kernels: correct, not tuned); the guidance models (Classifier,
-    EncoderPredictor) and ConvMFCCEncoder: powers of two.  Fail here, with the reason, rather than at handle creation."""
+    (widths other than 32 / 64 / 128 run generic forms of a few kernels: correct, not tuned), and so do the guidance models
+    (Classifier, EncoderPredictor) since round 6; ConvMFCCEncoder: powers of two.  Fail here, with the reason, rather than at handle
+    creation."""
     if base_channels % 32 or not 32 <= base_channels <= 256:
         raise ValueError(f"base_channels={base_channels}: the gfx950 library builds multiples of 32 in 32..256 "
                          "(every convolution works on 32-channel chunks); see INTEGRATION.md")
     if power_of_two and base_channels & (base_channels - 1):
-        raise ValueError(f"base_channels={base_channels}: this model's backward kernels need a power of two ({SUPPORTED_BASE_CHANNELS})")
+        raise ValueError(f"base_channels={base_channels}: this model's front-end kernels need a power of two ({SUPPORTED_BASE_CHANNELS})")
 
 
 
