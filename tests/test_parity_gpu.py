@@ -112,6 +112,19 @@ def test_conditioning_of_any_length_vs_oracle(dev):
             got = model.predictor(x.to(dev), ts.to(dev), cond=cond.to(dev), labels=labels.to(dev)).cpu()
             assert rel_rms(got, want) < tol, (prec, T, Lc, rel_rms(got, want))
     model.set_precision("fp32")
+    # a caller alternating between conditioning lengths gets the handle of a length back instead of a rebuild (a handle is built for
+    # one length code), with the same bits
+    p = model.predictor
+    x, ts = seeded((2, 1, 4096), 91).to(dev), torch.tensor([0.35, 0.8]).to(dev)
+    ca, cb = seeded((2, 512, 37), 92, 0.5).to(dev), seeded((2, 512, 5), 93, 0.5).to(dev)
+    ya = p(x, ts, cond=ca, labels=labels.to(dev))
+    ha = p._handle
+    yb = p(x, ts, cond=cb, labels=labels.to(dev))
+    assert p._handle is not ha and len(p.__dict__.get("_cond_handles", {})) == 1
+    assert torch.equal(p(x, ts, cond=ca, labels=labels.to(dev)), ya) and p._handle is ha
+    assert torch.equal(p(x, ts, cond=cb, labels=labels.to(dev)), yb)
+    p.invalidate()
+    assert not p.__dict__.get("_cond_handles")
     with pytest.raises(ValueError, match="expected cond of shape"):
         model.predictor(torch.zeros(2, 1, 4096, device=dev), torch.zeros(2, device=dev), cond=torch.zeros(2, 256, 16, device=dev), labels=labels.to(dev))
 

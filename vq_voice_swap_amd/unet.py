@@ -134,6 +134,10 @@ class _NativeModule(nn.Module):
         for h, _ in self.__dict__.pop("_alt_handles", {}).values():
             if h is not None:
                 h.close()
+        for h in self.__dict__.pop("_cond_handles", {}).values():
+            h.close()
+
+    COND_HANDLES_KEPT = 3  # handles of other conditioning lengths kept beside the current one (small ones only: ALT_HANDLE_KEEP_BYTES)
 
     # an alternate-precision handle larger than this is closed when its override ends instead of waiting beside the module's own
     # (weights + an activation arena sized for the largest batch and length it has seen: several GB at 64 clips of 4 s)
@@ -231,6 +235,26 @@ class _NativeModule(nn.Module):
         h = self._handle
         if h is not None and self._handle_key == key and h.cfg.max_batch >= B and h.cfg.max_T >= T:
             return h
+        if h is not None and self._handle_key[:4] == key[:4] and self._handle_key != key:
+            # Only the conditioning-length code differs (a caller alternating between cond lengths, e.g. clips of different duration
+            # encoded by one encoder): the handle is set aside instead of torn down -- a handle is built for one code (vqvs_cfg
+            # reserved[3]) -- and taken back when its length returns.  Small handles only; the oldest goes first.
+            kept = self.__dict__.setdefault("_cond_handles", {})
+            if h.device_bytes() <= self.ALT_HANDLE_KEEP_BYTES:
+                kept[self._handle_key] = h
+                while len(kept) > self.COND_HANDLES_KEPT:
+                    kept.pop(next(iter(kept))).close()
+            else:
+                h.close()
+            self._handle, self._handle_key = None, None
+            back = kept.pop(key, None)
+            if back is not None and back.cfg.max_batch >= B and back.cfg.max_T >= T:
+                self._handle, self._handle_key = back, key
+                return back
+            if back is not None:
+                B, T = max(B, back.cfg.max_batch), max(T, back.cfg.max_T)
+                back.close()
+            h = None
         if h is not None:
             same_shape_class = self._handle_key[:3] == key[:3]
             B = max(B, h.cfg.max_batch) if same_shape_class else B
@@ -253,6 +277,7 @@ class _NativeModule(nn.Module):
         d["_handle_key"] = None
         d.pop("_token_tensors", None)
         d.pop("_alt_handles", None)
+        d.pop("_cond_handles", None)
         return d
 
     def __deepcopy__(self, memo):
@@ -262,7 +287,7 @@ class _NativeModule(nn.Module):
         new = cls.__new__(cls)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            if k in ("_token_tensors", "_alt_handles"):
+            if k in ("_token_tensors", "_alt_handles", "_cond_handles"):
                 continue
             new.__dict__[k] = None if k in ("_handle", "_handle_key") else copy.deepcopy(v, memo)
         return new
@@ -373,9 +398,7 @@ class UNetPredictor(_NativeModule):
                 raise ValueError(f"expected cond of shape {(B, self.cond_channels)} x L, got {tuple(cond.shape)}")
             lens = {(T // 160 + 1 - 2) // 2 + 1: 1, T // 256: 0}
             code = lens.get(cond.shape[2], 1000 + cond.shape[2])
-            if code != self._cond_code:
-                self._cond_code = code
-                self.invalidate()
+            self._cond_code = code  # (part of the handle's key: handle() builds, or takes back, the handle of this length)
         if labels is not None:
             labels = labels.detach().to(device=x.device, dtype=torch.int64).contiguous()
             if labels.shape != (B,):
