@@ -63,7 +63,8 @@ typedef struct vqvs_model vqvs_model;
 
 typedef struct vqvs_cfg {
   int32_t kind;          /* VQVS_KIND_* */
-  int32_t base_channels; /* multiple of 32 in 32..256 (reference configs: 32, 64; tuned: 32, 64, 128); MFCC encoder: a power of two */
+  int32_t base_channels; /* multiple of 32 in 32..256 (reference configs: 32, 64; tuned: 32, 64, 128); MFCC encoder: a power of two;
+                            other widths of a predictor / encoder: the padded physical width, see reserved[4] */
   int32_t in_channels;   /* 1 (the reference's default and every caller's value, unet.py:25) .. 64; predictor / encoder handles only */
   int32_t out_channels;  /* predictor: 1 or a multiple of 32; encoder: multiple of 32 */
   int32_t cond_channels; /* 0 = unconditional (unet.py:46-47) */
@@ -74,7 +75,16 @@ typedef struct vqvs_cfg {
   int32_t debug_taps;    /* 1 = keep every block output resident for vqvs_debug_read_tap */
   /* VQVS_KIND_RESBLOCK only: */
   int32_t rb_cin, rb_cout, rb_resize /*0 none, 1 avg-pool/2, 2 nearest x2*/, rb_dilation, rb_emb_channels /*0 = no FiLM*/;
-  int32_t reserved[5];
+  int32_t reserved[5];   /* [0] dropout flag (key names), [1] / [2] per kind (above), [3] predictor: conditioning-length code (below),
+                            [4] predictor / encoder: the REAL base_channels of a width that is not a multiple of 32, 0 = base_channels.
+                            The reference takes any width (unet.py:17-30).  Such a model is built at the PHYSICAL width base_channels =
+                            2^k * q_p, where real = 2^k * q (q odd) and q_p = the next power of two >= q, widened until the product is
+                            a multiple of 32 (48 -> 64, 40 -> 64, 24 -> 32, 100 -> 128): channels come in blocks of q_p whose first q
+                            are the real ones, and the caller passes every parameter in the physical shapes of vqvs_param_info with
+                            entry c of a channel axis at (c / q) * q_p + c % q and zeros elsewhere (concatenated inputs and FiLM's
+                            (a | b) rows are whole numbers of blocks: one rule for every axis).  GroupNorm groups and counts follow the
+                            real width (unet.py:345-349); pad channels are exactly zero in every tensor.
+                            vq_voice_swap_amd/unet.py pad_state does this for the Python classes. */
   /* Topology of VQVS_KIND_PREDICTOR / VQVS_KIND_ENCODER / VQVS_KIND_CLASSIFIER (reference UNetPredictor.__init__ unet.py:17-30,
    * UNetEncoder.__init__ unet.py:188-196, ClassifierStem.__init__ classifier.py:52-58).  topology_set = 0: the reference's defaults -- channel_mult (1,1,2,2,2,4,4,8,8), depth_mult 2,
    * middle_dilations (4,8,16,32) / out_dilations () -- and the fields below are ignored.  topology_set = 1: they describe the

@@ -246,3 +246,32 @@ def test_weight_snapshot_token_and_copies():
     d.train()
     with pytest.raises(RuntimeError, match="dropout"):
         d.predictor._check_inference_only(torch.zeros(1))
+
+
+def test_padded_width_parameter_tables(lib_built):
+    """Widths that are not multiples of 32 (the reference takes any, unet.py:17-30): the handle is built at the padded physical width
+    (csrc/net.cpp pad_map) and the module's real-width parameters are spread into its table block by block -- every value kept, every
+    pad position zero, FiLM's (a | b) halves and concatenated inputs included."""
+    from vq_voice_swap_amd import UNetEncoder, UNetPredictor
+    from vq_voice_swap_amd.unet import pad_blocks, pad_state, physical_base
+
+    assert [physical_base(b) for b in (48, 40, 24, 20, 16, 8, 100, 36, 96, 150)] == [64, 64, 32, 32, 32, 32, 128, 64, 96, 256]
+    m = UNetPredictor(48, channel_mult=(1, 2, 2), middle_dilations=(4,), depth_mult=1, num_labels=3, cond_channels=64)
+    cfg = m._cfg()
+    assert (cfg.base_channels, cfg.reserved[4]) == (64, 48) and m.base_channels == 48
+    table, sd = _native.param_table(cfg), m.state_dict()
+    assert set(n for n, _ in table) == set(sd.keys())
+    q, qp = pad_blocks(48)
+    ps = pad_state(sd, table, q, qp)
+    for n, shape in table:
+        assert tuple(ps[n].shape) == shape, n
+        assert torch.equal(ps[n].abs().sum().double(), sd[n].detach().abs().sum().double()) or abs(float(ps[n].abs().sum() - sd[n].abs().sum())) < 1e-3, n
+    w, pw = sd["up_blocks.0.pre_cond.2.weight"].detach(), ps["up_blocks.0.pre_cond.2.weight"]  # [96][96 + 96 concatenated][3] -> [128][256][3]
+    assert torch.equal(pw[4 * 5 + 1, 4 * 40 + 2], w[3 * 5 + 1, 3 * 40 + 2]) and float(pw[3::4].abs().sum()) == 0.0 and float(pw[:, 3::4].abs().sum()) == 0.0
+    f, pf = sd["down_blocks.0.cond_layers.1.weight"].detach(), ps["down_blocks.0.cond_layers.1.weight"]  # FiLM rows (a | b), columns = the embedding
+    assert torch.equal(pf[64 + 4 * 2 + 1, 4 * 7], f[48 + 3 * 2 + 1, 3 * 7])
+    e = UNetEncoder(40, channel_mult=(1, 2, 4), depth_mult=1, out_channels=64)
+    assert (e._cfg().base_channels, e._cfg().reserved[4]) == (64, 40)
+    assert UNetPredictor(64)._cfg().reserved[4] == 0 and UNetPredictor(96)._cfg().reserved[4] == 0
+    with pytest.raises(ValueError, match="builds up to 256"):
+        UNetPredictor(300)

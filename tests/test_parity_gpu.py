@@ -185,8 +185,8 @@ def test_unusual_widths_vs_oracle(dev):
     xe = seeded((2, 1, 1024), 97, 0.3)
     wante = ref_cpu.unet_encoder(sde, 96, xe, topology=dict(channel_mult=(1, 2), out_dilations=(), depth_mult=2))
     assert rel_rms(e(xe.to(dev)).cpu(), wante) < FP32_REL
-    with pytest.raises(ValueError, match="multiples of 32"):
-        UNetPredictor(48)
+    with pytest.raises(ValueError, match="builds up to 256"):
+        UNetPredictor(300)  # (48, 40, ... are built at a padded width since round 6: test_widths_that_are_not_multiples_of_32_vs_oracle)
 
 
 def test_multi_channel_input_vs_oracle(dev):
@@ -684,3 +684,45 @@ def test_random_topologies_seeded_subset(dev):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_topology.py"), "2026", "20"], capture_output=True, text=True, timeout=1500)
     tail = r.stdout[-3000:] + r.stderr[-3000:]
     assert r.returncode == 0 and "cases 20" in r.stdout and r.stdout.rstrip().endswith("bad 0"), tail
+
+
+def test_widths_that_are_not_multiples_of_32_vs_oracle(dev):
+    """The reference takes ANY base_channels (unet.py:17-30; its GroupNorm halves the group count until it divides the width,
+    unet.py:345-349).  Widths that are not multiples of 32 are built at a padded physical width whose extra channels stay exactly
+    zero (csrc/net.cpp pad_map: 48 -> 64, 40 -> 64, 24 -> 32, 20 -> 32, 100 -> 128), with the reference's group structure: predictor
+    (labels, conditioning, FiLM, concatenating up blocks, default and custom topologies) and encoder against the oracle."""
+    from vq_voice_swap_amd import UNetEncoder, UNetPredictor
+
+    cases = [(48, dict(), dict(), 16384),  # the default nine-level topology at base 48 (widths 48 .. 384, built as 64 .. 512)
+             (40, dict(channel_mult=(1, 2, 2, 4), middle_dilations=(2, 8), depth_mult=1), dict(num_labels=3, cond_channels=64), 4096),
+             (24, dict(channel_mult=(1, 1, 2), middle_dilations=(4,), depth_mult=2), dict(num_labels=2), 2048),
+             (20, dict(channel_mult=(1, 3, 4), middle_dilations=(), depth_mult=1), dict(in_channels=2), 1024),
+             (100, dict(channel_mult=(1, 2), middle_dilations=(3,), depth_mult=1), dict(cond_channels=32), 1024)]
+    for i, (base, topo, kw, T) in enumerate(cases):
+        m = UNetPredictor(base, **topo, **kw)
+        det_init_((f"predictor.w{base}." + k, v) for k, v in m.state_dict().items())
+        m.eval()
+        sd = {"predictor." + k: v.detach().clone() for k, v in m.state_dict().items()}
+        x, ts = seeded((2, kw.get("in_channels", 1), T), 1200 + i), torch.tensor([0.25, 0.7])
+        call = {}
+        if "num_labels" in kw:
+            call["labels"] = torch.tensor([1, 0])
+        if "cond_channels" in kw:
+            call["cond"] = seeded((2, kw["cond_channels"], 11), 1300 + i, 0.5)
+        want = ref_cpu.unet_predictor(sd, base, x, ts, topology=topo or None, **call)
+        for prec, tol in (("fp32", FP32_REL), ("fp16", 6e-3)):
+            m.set_precision(prec)
+            got = m(x.to(dev), ts.to(dev), **{k: v.to(dev) for k, v in call.items()}).cpu()
+            assert got.shape == want.shape and rel_rms(got, want) < tol, (base, prec, rel_rms(got, want))
+        m.invalidate()
+    for i, (base, topo, oc, T) in enumerate([(40, dict(channel_mult=(1, 2, 4), out_dilations=(2,), depth_mult=1), 64, 2048),
+                                             (24, dict(), 96, 16384)]):
+        e = UNetEncoder(base, out_channels=oc, **topo)
+        det_init_((f"encoder.w{base}." + k, v) for k, v in e.state_dict().items())
+        e.eval()
+        sd = {"encoder." + k: v.detach().clone() for k, v in e.state_dict().items()}
+        x = seeded((2, 1, T), 1400 + i, 0.3)
+        want = ref_cpu.unet_encoder(sd, base, x, topology=topo or None)
+        got = e(x.to(dev)).cpu()
+        assert got.shape == want.shape and rel_rms(got, want) < FP32_REL, (base, rel_rms(got, want))
+        e.invalidate()

@@ -342,7 +342,9 @@ class Builder {
     for (auto& s : srcs) Ctot += s.C;
     const size_t g_off = blob_f32(gn_name + ".weight");
     const size_t b_off = blob_f32(gn_name + ".bias");
-    const int groups = gn_groups(Ctot);
+    // (a padded handle: the reference's groups and counts follow the REAL width, see pad_map)
+    const int Creal = (int)((long long)Ctot * real_base(m_->cfg) / m_->cfg.base_channels);
+    const int groups = gn_groups(Creal);
     const int lshift = srcs[0].lshift;
     Builder* self = this;
     std::vector<TensorH> S = srcs;
@@ -358,7 +360,7 @@ class Builder {
       for (int i = 0; i < a.nsrc; ++i) a.src[i] = GnSrc{self->statp(S[i].stats_off), ntiles_of(L, SR[i]), S[i].C};
       a.Ctot = Ctot;
       a.groups = groups;
-      a.inv_count = 1.0 / ((double)(Ctot / groups) * (double)L);
+      a.inv_count = 1.0 / ((double)(Creal / groups) * (double)L);
       a.gamma = reinterpret_cast<const float*>(self->wp(g_off));
       a.beta = reinterpret_cast<const float*>(self->wp(b_off));
       a.film = film ? self->miscp(film_misc_off) : nullptr;
@@ -914,6 +916,38 @@ int gn_groups(int ch) {  // unet.py:345-349
   return g;
 }
 
+// Widths that are not multiples of 32 (vqvs_cfg.reserved[4] = the REAL base_channels of a predictor / encoder, 0 = base_channels itself):
+// the handle is built at the PHYSICAL width base_channels = padded_base(real), whose channels come in blocks of q_p of which the
+// first q carry the real channels and the rest are zero (weights, biases, affine parameters and FiLM rows of the pad channels are
+// zero: a pad channel is exactly 0 in every tensor).  real = 2^k * q with q odd; q_p = the next power of two >= q, widened until
+// 2^k * q_p is a multiple of 32.  Every real width m * real is a multiple of q and every GroupNorm group of the reference
+// (unet.py:345-349: 32 groups halved until they divide the width -- a power of two) is a whole number of blocks, so the reference's
+// groups are runs of physical channels too: the zero channels add nothing to a group's sums, and only the group COUNT and the number
+// of values per group (inv_count) have to come from the real width.
+struct PadMap {
+  int q = 1, qp = 1;
+  int phys(int c) const { return (c / q) * qp + c % q; }
+};
+PadMap pad_map(int real) {
+  PadMap m;
+  int k = 0;
+  while (((real >> k) & 1) == 0 && k < 5) ++k;
+  m.q = real >> k;
+  m.qp = 1;
+  while (m.qp < m.q) m.qp <<= 1;
+  while (((1 << k) * m.qp) % 32) m.qp <<= 1;
+  if (real % 32 == 0) m.qp = m.q;  // (nothing to pad)
+  return m;
+}
+int padded_base(int real) {
+  const PadMap m = pad_map(real);
+  return real / m.q * m.qp;
+}
+int real_base(const vqvs_cfg& c) {
+  const bool unet = c.kind == VQVS_KIND_PREDICTOR || c.kind == VQVS_KIND_ENCODER;
+  return unet && c.reserved[4] > 0 ? c.reserved[4] : c.base_channels;
+}
+
 static int check_topology(const vqvs_cfg& c) {
   if (c.topology_set && c.kind != VQVS_KIND_PREDICTOR && c.kind != VQVS_KIND_ENCODER && c.kind != VQVS_KIND_CLASSIFIER)
     VQVS_FAIL(VQVS_ERR_ARG, "a custom topology is built for predictor, encoder and classifier handles only (kind %d)", c.kind);
@@ -1061,6 +1095,12 @@ static int check_cfg(const vqvs_cfg& c) {
   //  whose octet count is not a power of two; the MFCC encoder's 12 * base wide stack stays on powers of two)
   if (c.kind == VQVS_KIND_MFCC_ENCODER && (c.base_channels & (c.base_channels - 1)))
     VQVS_FAIL(VQVS_ERR_ARG, "base_channels must be a power of two for this kind of model (got %d)", c.base_channels);
+  if ((c.kind == VQVS_KIND_PREDICTOR || c.kind == VQVS_KIND_ENCODER) && c.reserved[4] != 0) {
+    // a padded handle (pad_map): reserved[4] = the real base_channels, base_channels = its physical width
+    if (c.reserved[4] < 1 || c.reserved[4] > c.base_channels || padded_base(c.reserved[4]) != c.base_channels)
+      VQVS_FAIL(VQVS_ERR_ARG, "real base_channels %d (reserved[4]) does not pad to base_channels %d (expected %d)", c.reserved[4], c.base_channels,
+                c.reserved[4] >= 1 ? padded_base(c.reserved[4]) : 0);
+  }
   if (c.in_channels < 1 || c.in_channels > 64) VQVS_FAIL(VQVS_ERR_ARG, "in_channels must be in 1..64 (got %d)", c.in_channels);
   if (c.in_channels != 1 && c.kind != VQVS_KIND_PREDICTOR && c.kind != VQVS_KIND_ENCODER)
     VQVS_FAIL(VQVS_ERR_ARG, "in_channels = %d: only predictor and encoder handles take more than one input channel (the classifier stem and the "
@@ -1160,9 +1200,16 @@ int build_model(vqvs_model* m, const float* const* hp) {
     for (auto* v : {&d, &mdl, &u})
       for (auto& sp : *v) sp.prefix = px + sp.prefix;
     // ---- embedding + all blocks' FiLM rows
-    std::vector<float> freqs(E / 2);
-    for (int i = 0; i < E / 2; ++i)  // wavegrad.py:361-369 (float32 tensor math)
-      freqs[i] = (float)(std::exp((double)(float)(-std::log(100.0 / 0.1)) * (double)i / (double)(E / 2 - 1))) * 100.0f;
+    std::vector<float> freqs(E / 2, 0.0f);
+    {
+      // wavegrad.py:361-369 (float32 tensor math) at the REAL embedding width 4 * real base; a padded handle keeps the real entries at
+      // their physical positions (the halves of the embedding -- cos | sin -- are whole numbers of blocks), pad entries are 0 and meet
+      // zero weight rows
+      const int Er = 4 * real_base(c);
+      const PadMap pm = pad_map(real_base(c));
+      for (int i = 0; i < Er / 2; ++i)
+        freqs[pm.phys(i)] = (float)(std::exp((double)(float)(-std::log(100.0 / 0.1)) * (double)i / (double)(Er / 2 - 1))) * 100.0f;
+    }
     const size_t freq_off = b.blob.add(freqs.data(), freqs.size() * 4);
     const size_t w1 = b.blob_f32_transposed(b.P(px + "time_embed.proj.weight"), E, E), b1 = b.blob_f32(px + "time_embed.proj.bias");
     const size_t w2 = b.blob_f32_transposed(b.P(px + "time_embed_extra.1.weight"), E, E), b2 = b.blob_f32(px + "time_embed_extra.1.bias");

@@ -107,6 +107,8 @@ int enumerate_params(const vqvs_cfg& cfg, std::vector<ParamDef>& out);
 int build_model(vqvs_model* m, const float* const* h_params);
 int run_model(vqvs_model* m, const RunCtx& ctx);
 int gn_groups(int ch);
+int real_base(const vqvs_cfg& c);  // the reference width of a padded predictor / encoder handle (vqvs_cfg.reserved[4]), else base_channels
+int padded_base(int real);
 int unet_rate(const vqvs_cfg& cfg);  // downsample rate of a predictor / encoder handle's topology (256 for the reference's default)
 int tensor_rows(int Lbase, int lshift);  // rows per clip of a tensor with length code `lshift` at base length Lbase
 }  // namespace vqvs

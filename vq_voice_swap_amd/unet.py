@@ -28,11 +28,60 @@ MIDDLE_DILATIONS = (4, 8, 16, 32)
 SUPPORTED_BASE_CHANNELS = (32, 64, 128)  # the tuned widths (the reference's two published ones and the next)
 
 
-def check_base_channels(base_channels: int, power_of_two: bool = False) -> None:
+def pad_blocks(base_channels: int) -> Tuple[int, int]:
+    """(q, q_p) of a width that is not a multiple of 32 (csrc/net.cpp pad_map): base = 2^k * q with q odd; the handle is built with
+    channels in blocks of q_p -- the next power of two >= q, widened until 2^k * q_p is a multiple of 32 -- whose first q channels
+    are the real ones and the rest stay exactly zero.  Multiples of 32: (q, q): nothing is padded."""
+    k = 0
+    while (base_channels >> k) & 1 == 0 and k < 5:
+        k += 1
+    q = base_channels >> k
+    if base_channels % 32 == 0:
+        return q, q
+    qp = 1
+    while qp < q:
+        qp <<= 1
+    while ((1 << k) * qp) % 32:
+        qp <<= 1
+    return q, qp
+
+
+def physical_base(base_channels: int) -> int:
+    q, qp = pad_blocks(base_channels)
+    return base_channels // q * qp
+
+
+def pad_state(state, table, q: int, qp: int):
+    """Real-width parameters -> the physical (zero-padded) shapes of a padded handle's parameter table: every axis whose size differs
+    is a channel axis -- a whole number of q-channel blocks, concatenations and FiLM's (a | b) halves included -- and its entry c goes to
+    (c // q) * qp + c % q; everything else is zero."""
+    out = {}
+    for name, shape in table:
+        t = state[name].detach().to(device="cpu", dtype=torch.float32)
+        for ax, (r, p_) in enumerate(zip(t.shape, shape)):
+            if r == p_:
+                continue
+            if r % q or r // q * qp != p_:
+                raise ValueError(f"parameter {name}: axis {ax} of size {r} does not pad to {p_} in blocks of {q} -> {qp}")
+            idx = torch.arange(r)
+            idx = (idx // q) * qp + idx % q
+            new = torch.zeros(*t.shape[:ax], p_, *t.shape[ax + 1:], dtype=t.dtype)
+            new.index_copy_(ax, idx, t)
+            t = new
+        out[name] = t
+    return out
+
+
+def check_base_channels(base_channels: int, power_of_two: bool = False, pad_ok: bool = False) -> None:
     """The reference accepts any `base_channels` (models/unet.py:17-30).  UNetPredictor / UNetEncoder: any multiple of 32 up to 256
-    (widths other than 32 / 64 / 128 run generic forms of a few kernels: correct, not tuned), and so do the guidance models
-    (Classifier, EncoderPredictor) since round 6; ConvMFCCEncoder: powers of two.  Fail here, with the reason, rather than at handle
-    creation."""
+    (widths other than 32 / 64 / 128 run generic forms of a few kernels: correct, not tuned) and, since round 6, ANY width whose padded
+    form (pad_blocks: 48 -> 64, 40 -> 64, 24 -> 32, 100 -> 128, ...) is at most 256 -- built at the padded width with zero channels;
+    the guidance models (Classifier, EncoderPredictor): multiples of 32; ConvMFCCEncoder: powers of two.  Fail here, with the reason,
+    rather than at handle creation."""
+    if pad_ok and int(base_channels) == base_channels and base_channels >= 1 and base_channels % 32:
+        if physical_base(base_channels) > 256:
+            raise ValueError(f"base_channels={base_channels}: pads to {physical_base(base_channels)} channels, the gfx950 library builds up to 256")
+        return
     if base_channels % 32 or not 32 <= base_channels <= 256:
         raise ValueError(f"base_channels={base_channels}: the gfx950 library builds multiples of 32 in 32..256 "
                          "(every convolution works on 32-channel chunks); see INTEGRATION.md")
@@ -266,7 +315,11 @@ class _NativeModule(nn.Module):
         cfg.max_T = T
         cfg.debug_taps = 1 if self.debug_taps else 0
         torch.cuda.synchronize(idx)
-        self._handle = _native.Handle(cfg, self.state_dict(), "", idx)
+        state = self.state_dict()
+        q, qp = pad_blocks(getattr(self, "base_channels", 32)) if cfg.reserved[4] else (1, 1)
+        if q != qp:  # a width that is not a multiple of 32: the handle takes the zero-padded physical shapes
+            state = pad_state(state, _native.param_table(cfg), q, qp)
+        self._handle = _native.Handle(cfg, state, "", idx)
         self._handle_key = key
         return self._handle
 
@@ -310,8 +363,8 @@ class UNetPredictor(_NativeModule):
                  cond_channels: Optional[int] = None, num_labels: Optional[int] = None,
                  in_channels: int = 1, out_channels: int = 1, dropout: float = 0.0):
         super().__init__()
-        check_base_channels(base_channels)
-        check_topology(base_channels, tuple(channel_mult), depth_mult, tuple(middle_dilations))
+        check_base_channels(base_channels, pad_ok=True)
+        check_topology(physical_base(base_channels), tuple(channel_mult), depth_mult, tuple(middle_dilations))
         if channel_mult[0] != 1:  # (the reference constructs such a model and fails in forward: its output head normalises base_channels, unet.py:113)
             raise ValueError("channel_mult[0] must be 1: the output head (GroupNorm + conv) is built for base_channels")
         self.base_channels = base_channels
@@ -363,7 +416,8 @@ class UNetPredictor(_NativeModule):
     def _cfg(self) -> _native.Cfg:
         cfg = _native.Cfg()
         cfg.kind = _native.KIND_PREDICTOR
-        cfg.base_channels = self.base_channels
+        cfg.base_channels = physical_base(self.base_channels)
+        cfg.reserved[4] = self.base_channels if cfg.base_channels != self.base_channels else 0  # (a padded handle: csrc/net.cpp pad_map)
         cfg.in_channels = self.in_channels
         cfg.out_channels = self.out_channels
         cfg.cond_channels = self.cond_channels or 0
@@ -441,8 +495,8 @@ class UNetEncoder(_NativeModule):
     def __init__(self, base_channels: int, channel_mult: Tuple[int, ...] = CHANNEL_MULT, out_dilations: Tuple[int, ...] = (),
                  depth_mult: int = 2, in_channels: int = 1, out_channels: int = 512):
         super().__init__()
-        check_base_channels(base_channels)
-        check_topology(base_channels, tuple(channel_mult), depth_mult, tuple(out_dilations))
+        check_base_channels(base_channels, pad_ok=True)
+        check_topology(physical_base(base_channels), tuple(channel_mult), depth_mult, tuple(out_dilations))
         self.base_channels = base_channels
         self.channel_mult = tuple(channel_mult)
         self.out_dilations = tuple(out_dilations)
@@ -467,7 +521,8 @@ class UNetEncoder(_NativeModule):
     def _cfg(self) -> _native.Cfg:
         cfg = _native.Cfg()
         cfg.kind = _native.KIND_ENCODER
-        cfg.base_channels = self.base_channels
+        cfg.base_channels = physical_base(self.base_channels)
+        cfg.reserved[4] = self.base_channels if cfg.base_channels != self.base_channels else 0  # (a padded handle: csrc/net.cpp pad_map)
         cfg.in_channels = self.in_channels
         cfg.out_channels = self.out_channels
         if (self.channel_mult, self.out_dilations, self.depth_mult) != (CHANNEL_MULT, (), 2):
