@@ -275,3 +275,22 @@ def test_padded_width_parameter_tables(lib_built):
     assert UNetPredictor(64)._cfg().reserved[4] == 0 and UNetPredictor(96)._cfg().reserved[4] == 0
     with pytest.raises(ValueError, match="builds up to 256"):
         UNetPredictor(300)
+
+
+def test_few_step_promotion_finds_the_native_modules():
+    """Diffusion.ddpm_sample promotes a guided run of fewer than FEW_GUIDED_STEPS steps to the fp32 mode: it has to find the native
+    modules behind whatever callables it is given -- the module itself, UNetPredictor.condition's partial, a bound method, the
+    guidance closures of Classifier / EncoderPredictor -- and nothing behind a plain function."""
+    from vq_voice_swap_amd import Classifier, EncoderPredictor, UNetPredictor
+    from vq_voice_swap_amd.diffusion import FEW_GUIDED_STEPS, _native_modules
+
+    p = UNetPredictor(32, num_labels=3)
+    clf = Classifier(num_labels=3, base_channels=32)
+    ep = EncoderPredictor(base_channels=32, downsample_rate=256, num_latents=8, bottleneck_dim=32)
+    assert FEW_GUIDED_STEPS == 10
+    assert _native_modules(p) == [p]
+    assert _native_modules(p.condition(labels=torch.zeros(1, dtype=torch.long))) == [p]
+    assert _native_modules(p.forward) == [p]
+    assert _native_modules(clf.guidance_fn(torch.zeros(1, dtype=torch.long), 2.0)) == [clf]
+    assert _native_modules(ep.guidance_fn(torch.zeros(1, 4, dtype=torch.long), 1.0)) == [ep]
+    assert _native_modules(lambda x, ts: x) == []
