@@ -164,6 +164,18 @@ def other_configs(dev, prec: str, T: int):
     return out
 
 
+def box_id(dev):
+    """Which box measured this line (boxes differ by +- 2 % on this workload: a number is only comparable with numbers of the same box)."""
+    import socket
+
+    p = torch.cuda.get_device_properties(dev)
+    out = {"hostname": socket.gethostname(), "gpu": p.name, "compute_units": p.multi_processor_count, "hbm_GB": round(p.total_memory / 2 ** 30, 1)}
+    uuid = getattr(p, "uuid", None)
+    if uuid is not None:
+        out["gpu_uuid"] = str(uuid)
+    return out
+
+
 def free_port() -> int:
     import socket
 
@@ -465,6 +477,7 @@ def main():
             "cpu_baseline": cpu,
             "other_modes": others,
             "other_configs": other_cfgs,
+            "box": box_id(dev),
             "parity": "dtype mode held to <= 1e-3 waveform RMS vs the CPU reference by tests/test_parity_gpu.py and tests/test_scale_gpu.py"
                       if a.precision in ("fp16", "fp32") else "dtype mode is OUTSIDE the 1e-3 waveform gate",
         }
