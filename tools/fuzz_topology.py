@@ -1,7 +1,7 @@
 """Randomised topology sweep (HIP vs oracle): UNetPredictor / UNetEncoder with random base width, channel_mult, depth_mult,
 middle / output dilations, labels, conditioning of random length, input channels and batch, at short lengths.  Developer tool;
 tests/ hold the fixed cases (fixture F14 from the reference, widths 96 / 160, multi-channel input).
-    python tools/fuzz_topology.py [seed] [cases]"""
+    python tools/fuzz_topology.py [seed] [cases] [odd]     ("odd": base widths that are NOT multiples of 32 -- built at a padded width)"""
 import os
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # kernel arguments in device memory: a process-level HIP switch, before the runtime starts
 import random, sys
@@ -12,19 +12,21 @@ from oracle import ref_cpu
 from vq_voice_swap_amd import UNetEncoder, UNetPredictor
 from vq_voice_swap_amd.det_init import det_init_
 from util import rel_rms, seeded
+from vq_voice_swap_amd.unet import physical_base as PHYS
 
 dev = torch.device("cuda:0")
 rng = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+ODD = len(sys.argv) > 3 and sys.argv[3] == "odd"
 torch.set_num_threads(8)
 bad = 0
 worst = {"fp32": 0.0, "fp16": 0.0}
 for i in range(N):
-    base = rng.choice([32, 32, 64, 96, 128])
+    base = rng.choice([8, 16, 20, 24, 36, 40, 48, 48, 72, 100]) if ODD else rng.choice([32, 32, 64, 96, 128])
     levels = rng.randint(1, 6)
     mult = [1]
     for _ in range(levels - 1):
-        mult.append(min(mult[-1] * rng.choice([1, 1, 2]), 1024 // base))
+        mult.append(min(mult[-1] * rng.choice([1, 1, 2]), 1024 // PHYS(base)))
     depth = rng.randint(1, 3)
     dil = [rng.choice([1, 2, 3, 4, 7, 16, 32]) for _ in range(rng.randint(0, 3))]
     rate = 2 ** (levels - 1)
