@@ -391,7 +391,9 @@ def test_vq_and_vqvae_vs_golden(golden, dev):
     model.set_precision("fp16")
     dec = model.decode(torch.from_numpy(z8["codes16"]).to(dev), torch.from_numpy(z8["labels"]).to(dev), steps=5, constrain=True,
                        x_T=x_T.to(dev), noise=noises).cpu()
-    gate("F8 vqvae32 decode 5 steps fp16 (not a gate claim)", dec, torch.from_numpy(z8["x0"]), None)
+    # (no 1e-3 claim at five un-guided steps in fp16 -- DESIGN.md section 4 -- but a numeric regression bound from the recorded margins:
+    #  0.8e-3 ... 1.1e-3 over rounds 3-6 by summation order)
+    gate("F8 vqvae32 decode 5 steps fp16 (not a gate claim: regression bound)", dec, torch.from_numpy(z8["x0"]), 2.5e-3)
     # F8b: 50 steps (BASELINE config 4), the reference's own output: fp32 AND fp16 inside 1e-3
     z8b = golden("f8b_vqvae_decode50")
     x_T = seeded((2, 1, 4096), int(z8b["x_T_seed"]))

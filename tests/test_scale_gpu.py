@@ -183,7 +183,7 @@ def test_config4_base64_decode_vs_oracle(dev):
     gen = torch.Generator().manual_seed(43)
     noises = [torch.randn(x_T.shape, generator=gen) for _ in range(steps)]
     want = ref_cpu.vqvae_decode(sd, 64, "exp", codes, labels, steps, x_T, noises, constrain=True)
-    for prec, bound in (("fp32", WAVE_RMS), ("fp16", None)):  # (fp16 at FIVE steps: recorded, not gated -- its gate is F8c, 50 steps)
+    for prec, bound in (("fp32", WAVE_RMS), ("fp16", 2.5e-3)):  # (fp16 at FIVE steps: no 1e-3 claim -- its gate is F8c, 50 steps -- but a regression bound: 6.2e-4 measured)
         model.set_precision(prec)
         got = model.decode(codes.to(dev), labels.to(dev), steps=steps, constrain=True, x_T=x_T.to(dev), noise=[n.to(dev) for n in noises]).cpu()
         gate(f"config 4 at base 64: VQVAE(64).decode {steps} steps, T = {T}, {prec}", got, want, bound)
